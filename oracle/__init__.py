@@ -1,0 +1,5 @@
+"""CPU oracle for the Gumbel-MuZero search hot path.
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg, never by the product package (muzero_amd).
+"""
