@@ -1,0 +1,180 @@
+/*
+ * muzero_hip.h - C ABI of libmuzero_hip.so: batched Gumbel-MuZero self-play search on MI355X.
+ *
+ * This is the drop-in boundary for ONE path of enpasos/muzero: the per-move
+ * search + inference that PlayService.playGames drives.  Every entry point names the reference
+ * interface it replaces.  Paths are relative to
+ *   platform/src/main/java/ai/enpasos/muzero/platform/   (abbreviated P/)
+ *
+ * Conventions
+ *  - plain C, opaque context, caller-owned flat buffers, int status (0 = ok, <0 = error; text via
+ *    mz_last_error).  One context per GPU; NOT thread-safe: call from one thread, like the
+ *    reference's single "model" thread (P/agent/d_model/service/ModelController.java:74-79).
+ *  - every data pointer may be a HOST pointer (FFM MemorySegment / JNI direct buffer) or a DEVICE
+ *    pointer (hipMalloc); the library detects which and stages host buffers itself.
+ *  - arrays over games are game-major: x[g * A + a].  A = action_space.
+ *  - trees, hidden states and network weights live in HBM for the lifetime of the context.
+ */
+#ifndef MUZERO_HIP_H
+#define MUZERO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mz_ctx mz_ctx;
+
+/* Network shape: the fields of MuZeroConfig the blocks read. */
+typedef struct mz_net_config {
+    int32_t height, width;      /* boardHeight, boardWidth */
+    int32_t obs_planes;         /* O: planes of Game.getObservationModelInput */
+    int32_t action_planes;      /* a: planes of Action.encode */
+    int32_t channels;           /* numChannels */
+    int32_t bottleneck;         /* numBottleneckChannels */
+    int32_t residuals;          /* numResiduals */
+    int32_t broadcast_every_n;  /* broadcastEveryN (0 = never) */
+    int32_t action_space;       /* actionSpaceSize */
+    int32_t two_players;        /* playerMode == TWO_PLAYERS */
+    double value_scale;         /* valueSpan / 2 (InitialInferenceListTranslator.java:94) */
+} mz_net_config;
+
+/* Search parameters: MuZeroConfig fields read by GumbelSearch / SequentialHalving / selectAction. */
+typedef struct mz_search_config {
+    int32_t num_simulations;         /* numSimulations (default n; per-game override in mz_search_moves) */
+    int32_t initial_gumbel_m;        /* initialGumbelM (>= 2) */
+    int32_t c_visit;                 /* cVisit */
+    int32_t known_bounds;            /* 0 = KnownBounds() adaptive, 1 = [bound_min, bound_max] */
+    int32_t hybrid;                  /* trainingTypeKey == HYBRID */
+    int32_t gumbel_action_selection; /* gumbelActionSelection */
+    double c_scale;                  /* cScale */
+    double discount;                 /* discount */
+    double bound_min, bound_max;
+    double root_exploration_fraction; /* rootExplorationFraction (Dirichlet noise is an input) */
+    double temperature_root;          /* temperatureRoot */
+} mz_search_config;
+
+enum { MZ_PRECISION_FP32 = 0, MZ_PRECISION_BF16 = 1 };
+
+typedef struct mz_config {
+    mz_net_config net;
+    mz_search_config search;
+    int32_t max_games;       /* capacity B of one mz_search_moves call (numParallelGamesPlayed) */
+    int32_t max_simulations; /* capacity for per-game num_simulations (>= search.num_simulations) */
+    int32_t precision;       /* MZ_PRECISION_* of the network forward */
+    int32_t pool_slots;      /* extra hidden-state slots for the inference-level API (may be 0) */
+} mz_config;
+
+/* Outputs of one planned move per game = what PlanAction.planAction + storeSearchStatistics +
+ * selectAction leave in GameDTO (P/agent/e_experience/GameDTO.java:42-77). Any pointer may be NULL. */
+typedef struct mz_move_outputs {
+    int32_t* action;                   /* [B]   returned Action.index                                  */
+    int32_t* selected_action;          /* [B]   GumbelSearch.selectedAction (sequential-halving winner) */
+    int32_t* visit_counts;             /* [B*A] root children visitCount by action (0 if illegal)       */
+    float* policy_target;              /* [B*A] GameDTO.policyTargets                                   */
+    float* root_value_target;          /* [B]   GameDTO.rootValueTargets                                */
+    float* v_mix;                      /* [B]   GameDTO.vMix                                            */
+    float* root_value_inference;       /* [B]   GameDTO.rootValuesFromInitialInference                  */
+    float* entropy;                    /* [B]   GameDTO.entropies                                       */
+    float* legal_action_max_entropy;   /* [B]   GameDTO.legalActionMaxEntropies                         */
+    float* root_entropy_value_target;  /* [B]   GameDTO.rootEntropyValueTargets                         */
+    float* playout_policy;             /* [B*A] GameDTO.playoutPolicy (valid where playout_appended)    */
+    uint8_t* playout_appended;         /* [B]                                                           */
+    int32_t* sims_run;                 /* [B]   simulations actually run for this move                  */
+    int32_t* status;                   /* [B]   0 ok; 1 = MuZeroException equivalent (see mz_last_error) */
+} mz_move_outputs;
+
+/* ---- lifecycle ------------------------------------------------------------------------------ */
+
+/* Replaces ModelController's model creation (P/agent/d_model/service/ModelController.java:119-152)
+ * for inference: allocates weights, trees and the hidden-state pool on `device`. */
+int mz_create(const mz_config* cfg, int device, mz_ctx** out);
+void mz_destroy(mz_ctx* ctx);
+const char* mz_last_error(const mz_ctx* ctx); /* ctx may be NULL: error of the failed mz_create */
+
+/* Action.encode tables (P/agent/a_loopcontrol/Action.java:34; TicTacToeAction.java:57-61,
+ * GoAction.java:67-73, PegSolitairAction.java:57-61): cells[i] = index of the single 1 in the
+ * [a,H,W] planes of action i, or -1 for an all-zero encoding (Go's pass). Default: i if i < a*H*W else -1. */
+int mz_set_action_cells(mz_ctx* ctx, const int32_t* cells);
+
+/* Replaces Network / model.load (P/agent/d_model/Network.java:96-100, ModelController.java:315-333).
+ * blob = fp32 tensors in the order documented in muzero_amd/netspec.py; count = number of floats. */
+int mz_load_weights(mz_ctx* ctx, const float* blob, size_t count);
+size_t mz_num_params(const mz_ctx* ctx);
+/* Device address of the fp32 master copy of the blob, for an in-place RCCL broadcast after a
+ * training epoch (BASELINE.json north_star); mz_commit_weights repacks it for the kernels. */
+int mz_weights_device_ptr(mz_ctx* ctx, void** ptr, size_t* bytes);
+int mz_commit_weights(mz_ctx* ctx);
+
+/* ---- inference level: ModelService.initialInference(List<Game>) / recurrentInference ----------
+ * (P/agent/d_model/service/ModelService.java:34-67,137-175; Network.java:172-231;
+ *  NetworkIO.java:39-52).  Hidden states stay in HBM; `*_slot` are indices into the context's pool
+ *  [0, pool_slots) and play the role of NetworkIO.hiddenState handles. */
+int mz_initial_inference(mz_ctx* ctx, int B, const float* obs /* [B*O*H*W] */, const int32_t* dst_slot /* [B] */,
+                         float* logits /* [B*A] */, float* policy /* [B*A] */, double* value /* [B] */);
+int mz_recurrent_inference(mz_ctx* ctx, int B, const int32_t* src_slot, const int32_t* action,
+                           const int32_t* dst_slot, float* logits, float* policy, double* value);
+int mz_read_hidden(mz_ctx* ctx, int32_t slot, float* out /* [C*H*W] */);
+
+/* ---- move level: PlanAction.planAction for B games in lock-step ---------------------------------
+ * (P/agent/c_planning/PlanAction.java:68-171 incl. the one-legal-action shortcut; GumbelSearch.java;
+ *  Node.java; SequentialHalving.java; called from PlayService.playGames, PlayService.java:110-146).
+ *  obs              [B*O*H*W]  Game.getObservationModelInput
+ *  legal            [B*A]      last entry of GameDTO.legalActions (Game.legalActions, Game.java:165-174)
+ *  to_play          [B]        0/1, Game.toPlay (NULL = 0)
+ *  num_simulations  [B]        config.getNumSimulations(game) (MuZeroConfig.java:343-362); NULL = default
+ *  gumbel           [B*A]      g per ACTION index (GumbelFunctions.drawGumble); NULL = withGumbel=false
+ *  dirichlet        [B*A]      Dirichlet sample per ACTION index (Functions.numpyRandomDirichlet);
+ *                              NULL => no noise even if root_exploration_fraction != 0
+ *  exploration_time [B]        Game.isItExplorationTime (Game.java:501-507); NULL = 0
+ *  u                [B]        uniform draw of Functions.draw (Functions.java:128-138); NULL = 0 */
+int mz_search_moves(mz_ctx* ctx, int B, const float* obs, const uint8_t* legal, const uint8_t* to_play,
+                    const int32_t* num_simulations, const double* gumbel, const double* dirichlet,
+                    const uint8_t* exploration_time, const double* u, const mz_move_outputs* out);
+
+/* Same search with the network replaced by pre-recorded outputs (bit-exactness tests: "given
+ * identical network outputs and Gumbel noise").  sim_* entry s of game g is what recurrentInference
+ * returns for the leaf created by simulation s: sim_logits/sim_policy [B*S*A], sim_value [B*S]. */
+int mz_search_moves_injected(mz_ctx* ctx, int B, const uint8_t* legal, const uint8_t* to_play,
+                             const int32_t* num_simulations, const float* init_logits, const float* init_policy,
+                             const double* init_value, const float* sim_logits, const float* sim_policy,
+                             const double* sim_value, int S, const double* gumbel, const double* dirichlet,
+                             const uint8_t* exploration_time, const double* u, const mz_move_outputs* out);
+
+/* Record the network outputs mz_search_moves uses, so a CPU replay can check the search bit for bit.
+ * After a recorded call: init_* as above, sim_* sized [B*S*A] / [B*S] with S = max_simulations. */
+int mz_set_recording(mz_ctx* ctx, int enable);
+int mz_get_recording(mz_ctx* ctx, float* init_logits, float* init_policy, double* init_value, float* sim_logits,
+                     float* sim_policy, double* sim_value);
+
+/* ---- introspection: Game.getSearchManager().getRoot() / Node getters (GumbelSearch.java:37,
+ * Node.java:48-78; used by renderers TicTacToeGame.java:192-206, GoGame.java:186-204) --------------
+ * Expanded node `slot` (0 = root, s+1 = leaf of simulation s) of game g after the last move search.
+ * scalars[8] = valueFromInference, vmix, improvedValue, qValueSum, vEntropyMix, improvedEntropyValue,
+ * entropyQValueSum, entropyReward.  child_* hold action_space entries, in the reference's child order.
+ * Returns the number of children, or <0. */
+int mz_tree_num_nodes(mz_ctx* ctx, int game);
+int mz_tree_node(mz_ctx* ctx, int game, int slot, int32_t* parent_slot, int32_t* action, int32_t* to_play,
+                 int32_t* visit_count, double* scalars, int32_t* child_action, double* child_prior,
+                 double* child_logit, int32_t* child_visit, double* child_qsum, int32_t* child_slot);
+int mz_tree_minmax(mz_ctx* ctx, int game, double* minimum, double* maximum);
+
+/* ---- measurement ------------------------------------------------------------------------------
+ * Device time (HIP events on the library's own stream) of the kernels of the last mz_search_moves /
+ * mz_*_inference call, by kind.  ms[i] = accumulated milliseconds, launches[i] = kernel launches. */
+enum { MZ_T_INITIAL = 0, MZ_T_RECURRENT = 1, MZ_T_TREE_ROOT = 2, MZ_T_TREE_SELECT = 3, MZ_T_TREE_BACKUP = 4,
+       MZ_T_TREE_FINISH = 5, MZ_T_COUNT = 6 };
+int mz_set_timing(mz_ctx* ctx, int enable);
+int mz_get_timing(mz_ctx* ctx, double* ms /* [MZ_T_COUNT] */, int64_t* launches /* [MZ_T_COUNT] */);
+/* Total simulations run / mean search-path length (nodes incl. root) of the last mz_search_moves call. */
+int mz_get_last_stats(mz_ctx* ctx, int64_t* simulations, double* mean_path_len);
+
+int mz_synchronize(mz_ctx* ctx);
+const char* mz_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MUZERO_HIP_H */

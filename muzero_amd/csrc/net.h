@@ -1,0 +1,56 @@
+// Device-side description of the representation / dynamics / prediction nets and the launchers of
+// the inference kernels (fp32 exact path and bf16 MFMA path).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mz {
+
+constexpr int kMaxResiduals = 24;
+
+struct NetDims {
+    int H, Wd, HW, O, a, C, Cb, R, A, two_players;
+    int bcast_every_n;
+    double value_scale;
+};
+
+// Offsets (in floats) into the packed fp32 weight buffer used by the fp32 kernel.
+struct BlockOff {
+    int type;  // 0 = bottleneck, 1 = broadcast
+    long long ln1g, ln1b, c1, ln2g, ln2b, c2, ln3g, ln3b, c3, ln4g, ln4b, c4, bw, bb;
+};
+struct TowerOff {
+    long long conv0;     // [Cin][9][CoutPad]
+    int cin0;            // input channels of conv0 (O or C+a)
+    BlockOff blocks[kMaxResiduals];
+};
+struct HeadOff {
+    long long pconv, plng, plnb, pfcw, pfcb;            // pconv [C][4], pfcw [2HW][A]
+    long long vconv, vlng, vlnb, vfc1w, vfc1b, vfc2w, vfc2b;  // vfc1w [HW][C]
+};
+struct NetProgramF32 {
+    TowerOff rep, dyn;
+    HeadOff head;
+    int c_pad, cb_pad;  // channel counts rounded up to a multiple of 4
+};
+
+// Batch I/O of one inference launch.  Hidden states are [slot][C][HW] fp32 in `pool`.
+struct NetIO {
+    const float* obs;         // initial: [B][O][HW]
+    const int* src_slot;      // recurrent: [B] (global slot)
+    const int* dst_slot;      // [B] (global slot)
+    const int* action;        // recurrent: [B]
+    const int* active;        // [B] or nullptr (all active)
+    const int* action_cells;  // [A]
+    float* pool;
+    float* logits;            // [B][A]
+    float* policy;            // [B][A]
+    double* value;            // [B]
+    int B;
+};
+
+size_t fp32_lds_bytes(const NetDims& d);
+void launch_net_fp32(hipStream_t st, bool initial, const NetDims& d, const NetProgramF32* prog_dev,
+                     const float* wbuf, const NetIO& io);
+
+}  // namespace mz

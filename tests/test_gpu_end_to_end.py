@@ -1,0 +1,101 @@
+"""-m gpu: mz_search_moves with the real networks.  The device records the network outputs it used;
+the CPU oracle replays the search on exactly those outputs and must reproduce actions and visit counts
+bit for bit, and the recorded root outputs must match the fp32 CPU forward within tolerance."""
+import numpy as np
+import pytest
+
+from muzero_amd import capi, netspec
+from oracle import search as osr
+from oracle.net import NetOracle
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _e2e(spec, case, B, seed, precision=capi.PRECISION_FP32, frac=0.0):
+    c = H.SEARCH_CASES[case]
+    n, m = c["n"], c["m"]
+    rng = np.random.default_rng(seed)
+    w = netspec.random_weights(spec, seed=seed)
+    ctx = capi.Context(capi.make_config(spec, n, m, c["c_visit"], known_bounds=c["bounds"],
+                                        root_exploration_fraction=frac, max_games=B, precision=precision))
+    ctx.load_weights(netspec.pack_blob(spec, w))
+    ctx.set_action_cells(netspec.action_cells_board(spec))
+    ctx.set_recording(True)
+    obs = H.synthetic_obs(rng, spec, B)
+    legal = H.random_legal(rng, B, spec.action_space)
+    to_play = rng.integers(0, 2, B).astype(np.uint8)
+    g = H.gumbel_noise(rng, B, spec.action_space)
+    dn = H.dirichlet_noise(rng, legal) if frac else None
+    got = ctx.search_moves(B, obs, legal, to_play=to_play, gumbel=g, dirichlet=dn)
+    rec = ctx.get_recording()
+    sims, mean_path = ctx.last_stats()
+    assert sims == int(got["sims_run"].sum())
+    assert 2.0 <= mean_path <= n + 1
+
+    ocfg = osr.make_config(spec.action_space, m, c["c_visit"], two_players=spec.two_players, known_bounds=c["bounds"],
+                           root_exploration_fraction=frac)
+    ob = osr.OracleBatch(ocfg, B)
+    exp = ob.run_injected(legal, to_play.astype(np.int32), n, rec["init_logits"], rec["init_policy"],
+                          rec["init_value"], rec["sim_logits"], rec["sim_policy"], rec["sim_value"], gumbel=g,
+                          dirichlet=dn)
+    assert (got["status"] == 0).all()
+    np.testing.assert_array_equal(got["action"], exp["action"])
+    np.testing.assert_array_equal(got["visit_counts"], exp["visit_counts"])
+    np.testing.assert_array_equal(got["sims_run"], exp["sims_run"])
+    np.testing.assert_array_equal(got["root_value_target"], exp["root_value_target"])
+    np.testing.assert_allclose(got["policy_target"], exp["policy_target"], rtol=0, atol=1.2e-7)
+
+    # the recorded root outputs are the network's: compare with the CPU forward
+    ref = NetOracle(spec, w)
+    _, r_lg, r_pol, r_val = ref.initial_inference(obs)
+    tol = 2e-4 if precision == capi.PRECISION_FP32 else 3e-2
+    np.testing.assert_allclose(rec["init_logits"], r_lg.numpy(), rtol=tol, atol=tol)
+    np.testing.assert_allclose(rec["init_policy"], r_pol.numpy(), rtol=tol, atol=tol)
+    np.testing.assert_allclose(rec["init_value"] / spec.value_scale, r_val.numpy() / spec.value_scale, rtol=tol, atol=tol)
+    ctx.close()
+    return got
+
+
+def test_end_to_end_tictactoe_shape_fp32():
+    _e2e(netspec.spec_tictactoe(), "tictactoe", B=32, seed=1)
+
+
+def test_end_to_end_go9_fp32():
+    _e2e(netspec.spec_go9(), "go9", B=16, seed=2)
+
+
+def test_end_to_end_go5_dirichlet_fp32():
+    _e2e(netspec.spec_go5(), "go5", B=16, seed=4, frac=0.25)
+
+
+def test_end_to_end_pegsolitair_fp32():
+    spec = netspec.spec_pegsolitair()
+    _e2e(spec, "pegsolitair", B=8, seed=6)
+
+
+def test_device_pointers_accepted():
+    """Inputs and outputs already resident in HBM (torch CUDA tensors) give the same results as host arrays."""
+    import torch
+    spec = netspec.spec_tiny()
+    c = H.SEARCH_CASES["tictactoe"]
+    B = 32
+    rng = np.random.default_rng(8)
+    w = netspec.random_weights(spec, seed=8)
+    ctx = capi.Context(capi.make_config(spec, c["n"], c["m"], c["c_visit"], known_bounds=c["bounds"], max_games=B))
+    ctx.load_weights(netspec.pack_blob(spec, w))
+    obs = H.synthetic_obs(rng, spec, B)
+    legal = H.random_legal(rng, B, spec.action_space)
+    g = H.gumbel_noise(rng, B, spec.action_space)
+    host = ctx.search_moves(B, obs, legal, gumbel=g)
+    dev = torch.device("cuda:0")
+    out = dict(action=torch.zeros(B, dtype=torch.int32, device=dev),
+               visit_counts=torch.zeros(B, spec.action_space, dtype=torch.int32, device=dev),
+               policy_target=torch.zeros(B, spec.action_space, dtype=torch.float32, device=dev))
+    ctx.search_moves(B, torch.from_numpy(obs).to(dev), torch.from_numpy(legal).to(dev),
+                     gumbel=torch.from_numpy(g).to(dev), outputs=out)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(out["action"].cpu().numpy(), host["action"])
+    np.testing.assert_array_equal(out["visit_counts"].cpu().numpy(), host["visit_counts"])
+    np.testing.assert_array_equal(out["policy_target"].cpu().numpy(), host["policy_target"])
+    ctx.close()

@@ -1,0 +1,101 @@
+"""-m gpu: initialInference / recurrentInference of the HIP path against the fp32 torch-CPU restatement
+of the reference blocks (oracle/net.py), through the C ABI's inference-level entry points.
+
+Tolerances (north_star: "network outputs must match the reference DJL forward within a stated
+fp32/bf16 tolerance"; the reference's own cross-backend precedent is allClose(1e-2, 1e-2),
+onnx/.../BlockTestHelper.java:36):
+  fp32 path: |diff| <= 2e-4 + 2e-4*|ref| on hidden state, logits, policy; value/value_scale likewise.
+  bf16 path: |diff| <= 3e-2 + 3e-2*|ref| on logits/hidden, 2e-2 on policy and value/value_scale.
+"""
+import numpy as np
+import pytest
+
+from muzero_amd import capi, netspec
+from oracle.net import NetOracle
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+TOL = {capi.PRECISION_FP32: dict(h=2e-4, l=2e-4, p=2e-4, v=2e-4),
+       capi.PRECISION_BF16: dict(h=3e-2, l=3e-2, p=2e-2, v=2e-2)}
+
+
+def _specs():
+    return {
+        "tiny_bcast": netspec.spec_tiny(),                                    # 12 channels, broadcast block at idx 1
+        "tiny_single": netspec.spec_tiny(two_players=False, action_space=20, hw=(4, 5), obs=2, act=3,
+                                         residuals=3, broadcast_every_n=0, channels=8, bottleneck=4),
+        "tictactoe": netspec.spec_tictactoe(),
+        "go5": netspec.spec_go5(),
+        "go9": netspec.spec_go9(),
+        "pegsolitair": netspec.spec_pegsolitair(),
+    }
+
+
+def _check(spec, precision, B, seed, ln_jitter=0.1):
+    rng = np.random.default_rng(seed)
+    w = netspec.random_weights(spec, seed=seed, ln_jitter=ln_jitter)
+    blob = netspec.pack_blob(spec, w)
+    cells = netspec.action_cells_board(spec)
+    ctx = capi.Context(capi.make_config(spec, 4, 2, 50, max_games=B, precision=precision, pool_slots=2 * B))
+    assert ctx.num_params() == netspec.num_params(spec) == blob.size
+    ctx.load_weights(blob)
+    ctx.set_action_cells(cells)
+    ref = NetOracle(spec, w)
+    tol = TOL[precision]
+
+    obs = H.synthetic_obs(rng, spec, B)
+    slots0 = np.arange(B, dtype=np.int32)
+    lg, pol, val = ctx.initial_inference(obs, slots0)
+    r_state, r_lg, r_pol, r_val = ref.initial_inference(obs)
+    hid = np.stack([ctx.read_hidden(s) for s in slots0])
+    np.testing.assert_allclose(hid, r_state.numpy(), rtol=tol["h"], atol=tol["h"])
+    np.testing.assert_allclose(lg, r_lg.numpy(), rtol=tol["l"], atol=tol["l"])
+    np.testing.assert_allclose(pol, r_pol.numpy(), rtol=tol["p"], atol=tol["p"])
+    np.testing.assert_allclose(val / spec.value_scale, r_val.numpy() / spec.value_scale, rtol=tol["v"], atol=tol["v"])
+    assert np.abs(pol.sum(1) - 1).max() < 1e-5
+    assert hid.min() >= 0.0 and hid.max() <= 1.0 + 1e-6          # RescaleBlockExt range
+
+    # recurrent step from the device-resident hidden states, including the last action (Go: pass -> zero plane)
+    action = rng.integers(0, spec.action_space, B).astype(np.int32)
+    action[0] = spec.action_space - 1
+    slots1 = slots0 + B
+    lg2, pol2, val2 = ctx.recurrent_inference(slots0, action, slots1)
+    # reference step from the DEVICE hidden state so that errors do not compound across the two calls
+    r_state2, r_lg2, r_pol2, r_val2 = ref.recurrent_inference(hid, action, cells)
+    hid2 = np.stack([ctx.read_hidden(s) for s in slots1])
+    np.testing.assert_allclose(hid2, r_state2.numpy(), rtol=tol["h"], atol=tol["h"])
+    np.testing.assert_allclose(lg2, r_lg2.numpy(), rtol=tol["l"], atol=tol["l"])
+    np.testing.assert_allclose(pol2, r_pol2.numpy(), rtol=tol["p"], atol=tol["p"])
+    np.testing.assert_allclose(val2 / spec.value_scale, r_val2.numpy() / spec.value_scale, rtol=tol["v"],
+                               atol=tol["v"])
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", ["tiny_bcast", "tiny_single", "tictactoe", "go5", "go9", "pegsolitair"])
+def test_fp32_forward_matches_oracle(name):
+    _check(_specs()[name], capi.PRECISION_FP32, B=6, seed=3)
+
+
+def test_fp32_forward_zero_input():
+    # the reference's BlockTest also feeds zeros (BlockTest.java:35-147)
+    spec = netspec.spec_tiny()
+    w = netspec.random_weights(spec, seed=5, ln_jitter=0.1)
+    ctx = capi.Context(capi.make_config(spec, 4, 2, 50, max_games=2, pool_slots=4))
+    ctx.load_weights(netspec.pack_blob(spec, w))
+    obs = np.zeros((2, spec.obs_planes, spec.height, spec.width), np.float32)
+    lg, pol, val = ctx.initial_inference(obs, np.array([0, 1], np.int32))
+    r = NetOracle(spec, w).initial_inference(obs)
+    np.testing.assert_allclose(lg, r[1].numpy(), rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(val, r[3].numpy(), rtol=2e-4, atol=2e-4)
+    ctx.close()
+
+
+def test_weight_blob_size_is_checked():
+    spec = netspec.spec_tiny()
+    ctx = capi.Context(capi.make_config(spec, 4, 2, 50, max_games=1, pool_slots=2))
+    with pytest.raises(capi.MuZeroError):
+        ctx.load_weights(np.zeros(17, np.float32))
+    with pytest.raises(capi.MuZeroError):       # inference before weights are loaded
+        ctx.initial_inference(np.zeros((1, 3, 3, 3), np.float32), np.array([0], np.int32))
+    ctx.close()
