@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""Headline benchmark: MCTS simulations/sec of batched Gumbel-MuZero self-play search, Go 9x9.
+
+One "step" = one planned move for every game of the batch through the C ABI (mz_search_moves):
+initialInference of all roots, root expansion + Gumbel top-m, then n x [select -> recurrentInference
+of all leaves -> expand/backup/sequential halving], then storeSearchStatistics + selectAction.
+Inputs (observations, legal masks, Gumbel noise) and outputs are resident in HBM during the timed
+region.  Games shard over GPUs (one process per GPU, no data-path collective); RCCL only broadcasts
+the weight blob before the timed region and gathers the per-rank statistics after it.
+
+  python bench.py --gpus 1 --steps 3 --warmup 1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0}   # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    # name: (spec factory name, n, m, c_visit, known bounds)   SURVEY.md §8a-0
+    "go9": ("go9", 50, 16, 50, (-81.0, 81.0)),
+    "go5": ("go5", 30, 16, 50, (-25.0, 25.0)),
+    "tictactoe": ("tictactoe", 20, 4, 20, (-1.0, 1.0)),
+    "pegsolitair": ("pegsolitair", 100, 16, 50, None),
+}
+
+
+def cpu_baseline(spec, weights, n, m, c_visit, bounds, games, seed, max_batch=1000):
+    """The oracle search + fp32 torch-CPU forward, driven with the reference's batching policy (all
+    games in lock-step, <= numParallelInferences = 1000 samples per forward, ModelController.java:86-89).
+    Bounded sample: `games` games x one move."""
+    import torch
+    from oracle import search as osr
+    from oracle.net import NetOracle
+    from muzero_amd import netspec
+
+    rng = np.random.default_rng(seed)
+    A = spec.action_space
+    obs = (rng.uniform(size=(games, spec.obs_planes, spec.height, spec.width)) < 0.3).astype(np.float32)
+    legal = np.ones((games, A), np.uint8)
+    u = rng.uniform(size=(games, A))
+    gumbel = -np.log(-np.log(u))
+    cells = netspec.action_cells_board(spec)
+    net = NetOracle(spec, weights)
+    ob = osr.OracleBatch(osr.make_config(A, m, c_visit, two_players=spec.two_players, known_bounds=bounds), games)
+    chw = (spec.channels, spec.height, spec.width)
+    hidden = torch.zeros((games, n + 1) + chw)
+
+    def fwd_chunks(fn, count):
+        outs = []
+        for s in range(0, count, max_batch):
+            outs.append(fn(slice(s, min(count, s + max_batch))))
+        return [torch.cat([o[i] for o in outs]) for i in range(4)]
+
+    t0 = time.perf_counter()
+    st, lg, pol, val = fwd_chunks(lambda sl: net.initial_inference(obs[sl]), games)
+    hidden[:, 0] = st
+    ob.begin(legal, np.zeros(games, np.int32), n, lg.numpy(), pol.numpy(), val.numpy(), gumbel=gumbel)
+    nodes = np.ones(games, np.int64)
+    sims = 0
+    ar = np.arange(games)
+    while True:
+        cnt, ps, ac, on = ob.select()
+        if cnt == 0:
+            break
+        parent = hidden[ar, np.maximum(ps, 0)]
+        st, lg, pol, val = fwd_chunks(lambda sl: net.recurrent_inference(parent[sl], ac[sl], cells), games)
+        act = on.astype(bool)
+        hidden[ar[act], nodes[act]] = st[act]
+        nodes[act] += 1
+        ob.expand_backup(on, lg.numpy(), pol.numpy(), val.numpy())
+        sims += int(cnt)
+    out = ob.finish()
+    dt = time.perf_counter() - t0
+    assert (out["status"] == 0).all()
+    return sims / dt, sims, dt, torch.get_num_threads()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="go9", choices=sorted(WORKLOADS))
+    ap.add_argument("--games", type=int, default=4096, help="concurrent games per GPU")
+    ap.add_argument("--precision", default="bf16", choices=["fp32", "bf16"])
+    ap.add_argument("--cpu-games", type=int, default=2048, help="games in the bounded CPU-baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from muzero_amd import capi, netspec
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    spec_name, n, m, c_visit, bounds = WORKLOADS[args.workload]
+    spec = netspec.SPECS[spec_name]()
+    B, A = args.games, spec.action_space
+    precision = capi.PRECISION_BF16 if args.precision == "bf16" else capi.PRECISION_FP32
+    ctx = capi.Context(capi.make_config(spec, n, m, c_visit, known_bounds=bounds, max_games=B, precision=precision),
+                       device=local_rank)
+    ctx.set_action_cells(netspec.action_cells_board(spec))
+
+    # weights: rank 0 draws them, RCCL broadcasts the blob over xGMI, every rank repacks locally
+    weights = netspec.random_weights(spec, seed=1) if rank == 0 or world == 1 else None
+    if world > 1:
+        wt = torch.empty(netspec.num_params(spec), dtype=torch.float32, device=dev)
+        if rank == 0:
+            wt.copy_(torch.from_numpy(netspec.pack_blob(spec, weights)))
+        dist.broadcast(wt, src=0)
+        torch.cuda.synchronize()
+        ctx.load_weights(wt)
+    else:
+        ctx.load_weights(netspec.pack_blob(spec, weights))
+
+    # synthetic games: random 0/1 planes of density 0.3, all actions legal, device Gumbel noise
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1000 + rank)
+    obs = (torch.rand((B, spec.obs_planes, spec.height, spec.width), generator=gen, device=dev) < 0.3).float()
+    legal = torch.ones((B, A), dtype=torch.uint8, device=dev)
+    outs = dict(action=torch.zeros(B, dtype=torch.int32, device=dev),
+                visit_counts=torch.zeros((B, A), dtype=torch.int32, device=dev),
+                policy_target=torch.zeros((B, A), dtype=torch.float32, device=dev),
+                root_value_target=torch.zeros(B, dtype=torch.float32, device=dev),
+                sims_run=torch.zeros(B, dtype=torch.int32, device=dev),
+                status=torch.zeros(B, dtype=torch.int32, device=dev))
+
+    def draw_gumbel():
+        u = torch.rand((B, A), generator=gen, device=dev, dtype=torch.float64).clamp_(1e-300, 1.0 - 1e-16)
+        return -torch.log(-torch.log(u))
+
+    def sync():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    def step(g):
+        ctx.search_moves(B, obs, legal, gumbel=g, outputs=outs)
+
+    for _ in range(args.warmup):
+        step(draw_gumbel())
+    noise = [draw_gumbel() for _ in range(args.steps)]
+    ctx.set_timing(True)
+    sims_total = 0
+    kernel_ms = {k: 0.0 for k in capi.T_NAMES}
+    kernel_launches = {k: 0 for k in capi.T_NAMES}
+    path_sum = 0.0
+    sync()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(noise[k])
+        s, mp = ctx.last_stats()
+        sims_total += s
+        path_sum += mp * s
+        for name, (ms, cnt) in ctx.get_timing().items():
+            kernel_ms[name] += ms
+            kernel_launches[name] += cnt
+    sync()
+    dt = time.perf_counter() - t0
+    assert int(outs["status"].abs().sum().item()) == 0
+
+    # whole-job aggregate: MAX time over ranks, SUM of simulations (episode statistics gathered over RCCL)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        stats = torch.tensor([float(sims_total)], dtype=torch.float64, device=dev)
+        gathered = [torch.zeros_like(stats) for _ in range(world)]
+        dist.all_gather(gathered, stats)
+        dt = float(t.item())
+        sims_all = int(sum(float(x.item()) for x in gathered))
+    else:
+        sims_all = sims_total
+
+    if rank == 0:
+        fl = netspec.flops_per_sample(spec)
+        rec_ms, rec_n = kernel_ms["recurrent"], max(kernel_launches["recurrent"], 1)
+        avg_s = rec_ms / rec_n / 1e3
+        achieved = fl["recurrent"] * B / avg_s / 1e12 if avg_s > 0 else 0.0
+        peak = PEAK_TFLOPS[args.precision]
+        mean_path = path_sum / max(sims_total, 1)
+        tree_bytes = A * (12 * (mean_path - 2) + 28 + 8 + 20 * (mean_path - 1))
+        tree_ms = kernel_ms["tree_select"] + kernel_ms["tree_backup"]
+        line = {
+            "metric": "MCTS simulations/sec",
+            "value": sims_all / dt,
+            "unit": "simulations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.precision,
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload} self-play search, {B} concurrent games per GPU, "
+                                   f"n={n} simulations, m={m}, C={spec.channels}, R={spec.residuals}",
+                       "games_per_gpu": B, "num_simulations": n, "parallelism": f"games sharded x{world}"},
+            "roofline": {"bound": "mfma", "kernel": "recurrentInference", "achieved": achieved, "peak": peak,
+                         "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                         "flops_per_launch": fl["recurrent"] * B, "avg_launch_ms": rec_ms / rec_n},
+            "tree_kernels": {"bound": "hbm", "mean_path_len": mean_path, "algorithmic_bytes_per_sim": tree_bytes,
+                             "achieved_GBps": (tree_bytes * sims_total / (tree_ms / 1e3) / 1e9) if tree_ms else None,
+                             "peak_GBps": 8000.0},
+            "kernel_ms": {k: round(v, 3) for k, v in kernel_ms.items()},
+        }
+        if not args.no_cpu_baseline:
+            w_cpu = weights if weights is not None else netspec.random_weights(spec, seed=1)
+            v, sims, secs, threads = cpu_baseline(spec, w_cpu, n, m, c_visit, bounds, args.cpu_games, seed=1000)
+            line["cpu_baseline"] = {"value": v, "unit": "simulations/s", "cores": threads, "kind": "port",
+                                    "sample": f"{args.cpu_games} games x 1 move ({sims} simulations, {secs:.1f} s): "
+                                              "oracle search + fp32 torch-CPU forward, lock-step batches <= 1000"}
+        print(json.dumps(line), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

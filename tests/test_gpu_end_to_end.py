@@ -52,7 +52,9 @@ def _e2e(spec, case, B, seed, precision=capi.PRECISION_FP32, frac=0.0):
     tol = 2e-4 if precision == capi.PRECISION_FP32 else 3e-2
     np.testing.assert_allclose(rec["init_logits"], r_lg.numpy(), rtol=tol, atol=tol)
     np.testing.assert_allclose(rec["init_policy"], r_pol.numpy(), rtol=tol, atol=tol)
-    np.testing.assert_allclose(rec["init_value"] / spec.value_scale, r_val.numpy() / spec.value_scale, rtol=tol, atol=tol)
+    vtol = tol if precision == capi.PRECISION_FP32 else 8e-2
+    np.testing.assert_allclose(rec["init_value"] / spec.value_scale, r_val.numpy() / spec.value_scale, rtol=vtol,
+                               atol=vtol)
     ctx.close()
     return got
 
@@ -99,3 +101,12 @@ def test_device_pointers_accepted():
     np.testing.assert_array_equal(out["visit_counts"].cpu().numpy(), host["visit_counts"])
     np.testing.assert_array_equal(out["policy_target"].cpu().numpy(), host["policy_target"])
     ctx.close()
+
+
+def test_end_to_end_go9_bf16_mfma():
+    # 20 games = 7 workgroup tiles of 3 boards, the last one ragged; search replay must stay bit-exact
+    _e2e(netspec.spec_go9(), "go9", B=20, seed=5, precision=capi.PRECISION_BF16)
+
+
+def test_end_to_end_pegsolitair_bf16_mfma():
+    _e2e(netspec.spec_pegsolitair(), "pegsolitair", B=8, seed=7, precision=capi.PRECISION_BF16)
