@@ -1,23 +1,28 @@
 // bf16 MFMA forward of initialInference (f o h) and recurrentInference (f o g) for gfx950.
 //
 // One 256-thread workgroup (4 wavefronts, one per SIMD, up to 512 VGPRs each) carries a tile of NB
-// whole boards through the ENTIRE network in one launch.  Every conv is the transposed GEMM
+// whole boards through a run of layers in one launch.  Every conv is the transposed GEMM
 //     Y[out-channel][column] = W[out-channel][k] * Act[k][column],   column = (board, cell),
 // on v_mfma_f32_32x32x16_bf16 with fp32 accumulation:
 //   * each wave owns 64 columns (2 column tiles of 32) and ALL channels of them, so the fp32 residual
-//     stream X lives in that wave's accumulator registers for the whole tower and the closing 1x1 conv
+//     stream X lives in that wave's accumulator registers for the whole run and the closing 1x1 conv
 //     of a block accumulates straight into it;
 //   * 1x1 convs that follow a LayerNorm take their B operand directly from the accumulator registers
 //     (no LDS, no lane movement; the weights are pre-permuted in k to the accumulator's row order);
 //   * 3x3 convs read their B operand from a bf16 [column][channel] image in LDS through 9 shifted
-//     neighbour offsets (zero row for off-board cells) - the implicit GEMM, never materialised;
+//     neighbour rows (a zero row for off-board cells) - the implicit GEMM, never materialised;
 //   * LayerNorm over (C,H,W) of a sample = per-column partial sums -> LDS -> per-board reduction,
 //     fused into the epilogue of the producing conv; ReLU, residual add, min-max rescale, softmax
 //     and the value scaling are fused too;
 //   * weights are packed on the host into 1 KiB MFMA A-fragments in exact execution order: one linear
-//     stream per tower that each wave prefetches through a 16-deep register ring (16 KiB in flight per
-//     wave) across layer and block boundaries.
-// HBM traffic per sample: parent hidden state in, child hidden state out, logits/policy/value out.
+//     stream per tower that each wave prefetches through a register ring (RING KiB in flight per wave)
+//     across layer and block boundaries.
+// A tower runs as 1..3 launches: [conv0 + bottleneck blocks] -> [broadcast block] -> [bottleneck
+// blocks + rescale + heads].  The split exists for the register allocator (the broadcast block's
+// live set spilled when it shared a kernel with the bottleneck blocks); between launches X travels
+// through the sample's own destination hidden-state slot, which is overwritten at the end anyway.
+// HBM traffic per sample: parent hidden state in, child hidden state out (+ X round trips at the
+// broadcast block), logits/policy/value out.
 //
 // Reference math: see net_fp32.hip / oracle/net.py (same citations).
 #include "net_mfma.h"
@@ -44,12 +49,16 @@ constexpr int ZROW = COLS;     // LDS row of zeros (off-board neighbours, padded
 constexpr int RING = 16;       // A-fragment prefetch depth per wave
 constexpr int MAXNB = 32;      // boards per workgroup upper bound (COLS / 9 = 28)
 
+enum { IN_OBS = 0, IN_HIDDEN = 1, IN_X = 2 };
+enum { OUT_X = 0, OUT_FINAL = 1 };
+
 struct TowerDev {
-    const u32x4* stream;   // A fragments in execution order (+ RING fragments of slack)
+    const u32x4* stream;   // A fragments in execution order (+ slack)
     const u32x4* gb;       // LayerNorm gamma/beta, fp16, [p][Cn/4]{g0..3,b0..3}
     const u32x4* wbf;      // broadcast-linear B fragments (bf16)
     const float* bb;       // broadcast-linear bias, padded to QT*32
     int type[kMaxResiduals];
+    int foff[kMaxResiduals];         // first fragment of the block in the stream
     long long gboff[kMaxResiduals];  // in u32x4 units
     int wboff[kMaxResiduals];        // broadcast blocks: offset into wbf (u32x4 units) / bb (floats)
     int bboff[kMaxResiduals];
@@ -68,7 +77,7 @@ struct HeadDev {
     const float* vfc2b; // [1]
 };
 struct LdsPlan {
-    int act_off, tb_off, colsum_off, bstat_off, meta_off, nbt_off, head_off, total;
+    int act_off, tb_off, colsum_off, bstat_off, meta_off, head_off, total;
     int tbs;  // TB row stride in bytes
     int kp, qt;
 };
@@ -88,39 +97,49 @@ __device__ __forceinline__ bf16x4 pack4(const float* y) {
     return r;
 }
 
-// Register ring over the linear A-fragment stream. Indices passed to get() are compile-time
-// constants after unrolling; advance() moves the origin by a multiple of RING fragments.
+// Register ring over the linear A-fragment stream: wave-uniform position (SGPRs) + 32-bit lane offset.
+// Indices passed to get() are compile-time constants after unrolling; advance() moves the origin.
 struct Ring {
     u32x4 s[RING];
-    const u32x4* p;
-    __device__ __forceinline__ void init(const u32x4* base, int lane) {
-        p = base + lane;
+    const char* base;
+    unsigned lane_off;
+    __device__ __forceinline__ u32x4 ld(int i) const {
+        return *reinterpret_cast<const u32x4*>(base + (size_t)i * 1024 + lane_off);
+    }
+    __device__ __forceinline__ void init(const u32x4* b, int lane) {
+        base = reinterpret_cast<const char*>(b);
+        lane_off = (unsigned)lane * 16u;
 #pragma unroll
-        for (int i = 0; i < RING; i++) s[i] = p[i * 64];
+        for (int i = 0; i < RING; i++) s[i] = ld(i);
     }
     __device__ __forceinline__ bf16x8 get(int i) {
         u32x4 r = s[i % RING];
-        s[i % RING] = p[(i + RING) * 64];
+        s[i % RING] = ld(i + RING);
+        // Pin the refill HERE: without this the scheduler sinks each load down to just before its use
+        // (to shorten the live range) and the ring stops hiding any latency.  0x38F = everything except
+        // vector-memory instructions may still be scheduled across this point.
+        __builtin_amdgcn_sched_barrier(0x38F);
         return __builtin_bit_cast(bf16x8, r);
     }
-    __device__ __forceinline__ void advance(int nfrags) { p += (long long)nfrags * 64; }
+    __device__ __forceinline__ void advance(int nfrags) { base += (size_t)nfrags * 1024; }
 };
 
 struct Cols {
-    int col[TC];     // column index in the workgroup
-    int p[TC];       // cell within the board (0 for padded columns)
-    int board[TC];   // board within the tile (MAXNB for padded columns -> neutral statistics)
-    bool valid[TC];  // col < NB*HW
-    bool live[TC];   // valid and the board is an active sample
-    int nb[TC][9];   // LDS row of each 3x3 neighbour (ZROW if off-board)
+    int col[TC];          // column index in the workgroup
+    int p[TC];            // cell within the board (0 for padded columns)
+    int board[TC];        // board within the tile (MAXNB for padded columns -> neutral statistics)
+    bool valid[TC];       // col < NB*HW
+    bool live[TC];        // valid and the board is an active sample
+    unsigned nbmask[TC];  // bit t set: 3x3 neighbour t of this cell is on the board
 };
 
 struct Ctx {
     char* smem;
     LdsPlan L;
-    int HW, NB, lane, wave, h, r;
+    int HW, NB, Wd, lane, wave, h, r;
     float* colsum;   // [COLS][2]
-    float* bstat;    // [MAXNB+1][2]
+    float* bstat;    // [MAXNB+1][2] (+ per-wave partials in the broadcast kernel)
+    int* meta;       // [4][MAXNB]: src slot, dst slot, live, action cell
 };
 
 // Per-board reduction of per-column partials. MODE 0: (sum, sumsq) -> (mean, rstd); MODE 1: (min, max).
@@ -214,13 +233,17 @@ __device__ __forceinline__ void ln_stats(const Ctx& c, const Cols& k, const f32x
     board_reduce<0>(c, k, mean, rstd, 1.0f / (float)(nch * c.HW));
 }
 
-// gamma/beta of row tile rt for both column tiles: 4 x 16-byte loads per column.
+// gamma/beta of row tile rt for both column tiles: 4 x 16-byte loads per column
+// (uniform base + 32-bit per-lane offset + immediate).
 __device__ __forceinline__ void gb_load(const u32x4* gb, int cn4, const Ctx& c, const Cols& k, int rt,
                                         u32x4 (&g)[TC][4]) {
 #pragma unroll
-    for (int ct = 0; ct < TC; ct++)
+    for (int ct = 0; ct < TC; ct++) {
+        const unsigned off = (unsigned)(k.p[ct] * cn4 + c.h) * 16u;
 #pragma unroll
-        for (int qd = 0; qd < 4; qd++) g[ct][qd] = gb[(long long)k.p[ct] * cn4 + 8 * rt + 2 * qd + c.h];
+        for (int qd = 0; qd < 4; qd++)
+            g[ct][qd] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(gb) + off + (8 * rt + 2 * qd) * 16);
+    }
 }
 
 // y = relu((v - mean) * rstd * gamma + beta) for the 16 accumulator rows of one (row tile, column tile).
@@ -249,10 +272,9 @@ __device__ __forceinline__ void act_store(char* act, int rs, int col, int rt, in
 // out[ro][ct] += W * relu(LN(in)) with the B operand taken from the accumulator registers `in`.
 // Fragment order in the stream: (rt_in, s, ro).
 template <int NRI, int NRO>
-__device__ __forceinline__ void conv1x1_regfed(const Ctx& c, const Cols& k, Ring& ring, int& fi, const u32x4* gb,
-                                               const f32x16 (&in)[NRI][TC], f32x16 (&out)[NRO][TC]) {
-    float mean[TC], rstd[TC];
-    ln_stats<NRI>(c, k, in, NRI * 32, mean, rstd);
+__device__ __forceinline__ void conv1x1_regfed_core(const Ctx& c, const Cols& k, Ring& ring, int& fi, const u32x4* gb,
+                                                    const f32x16 (&in)[NRI][TC], f32x16 (&out)[NRO][TC],
+                                                    const float (&mean)[TC], const float (&rstd)[TC]) {
     u32x4 g[TC][4];
     gb_load(gb, NRI * 8, c, k, 0, g);
 #pragma unroll
@@ -276,12 +298,23 @@ __device__ __forceinline__ void conv1x1_regfed(const Ctx& c, const Cols& k, Ring
             }
     }
 }
+template <int NRI, int NRO>
+__device__ __forceinline__ void conv1x1_regfed(const Ctx& c, const Cols& k, Ring& ring, int& fi, const u32x4* gb,
+                                               const f32x16 (&in)[NRI][TC], f32x16 (&out)[NRO][TC]) {
+    float mean[TC], rstd[TC];
+    ln_stats<NRI>(c, k, in, NRI * 32, mean, rstd);
+    conv1x1_regfed_core<NRI, NRO>(c, k, ring, fi, gb, in, out, mean, rstd);
+}
 
-// LN + ReLU of `in` (NRI row tiles) into the LDS image, then out = conv(image) over TAPS taps.
-// Fragment order: (tap, ks, ro).  TAPS == 9: 3x3 with neighbour rows k.nb; TAPS == 1: centre tap only.
-template <int NRI, int NRO, int TAPS>
-__device__ __forceinline__ void conv_ldsfed(const Ctx& c, const Cols& k, Ring& ring, int& fi, const u32x4* gb,
-                                            const f32x16 (&in)[NRI][TC], f32x16 (&out)[NRO][TC]) {
+__device__ __forceinline__ int nb_row(const Ctx& c, const Cols& k, int ct, int t) {
+    return ((k.nbmask[ct] >> t) & 1u) ? k.col[ct] + (t / 3 - 1) * c.Wd + (t % 3 - 1) : ZROW;
+}
+
+// LN + ReLU of `in` (NRI row tiles) into the LDS image, then out += conv3x3(image).
+// Fragment order: (tap, ks, ro).
+template <int NRI, int NRO>
+__device__ __forceinline__ void conv3x3_ldsfed(const Ctx& c, const Cols& k, Ring& ring, int& fi, const u32x4* gb,
+                                               const f32x16 (&in)[NRI][TC], f32x16 (&out)[NRO][TC]) {
     constexpr int RS = NRI * 64 + 16;
     char* act = c.smem + c.L.act_off;
     float mean[TC], rstd[TC];
@@ -303,15 +336,16 @@ __device__ __forceinline__ void conv_ldsfed(const Ctx& c, const Cols& k, Ring& r
     }
     lds_barrier();
 #pragma unroll
-    for (int t = 0; t < TAPS; t++)
+    for (int t = 0; t < 9; t++) {
+        int row[TC];
+#pragma unroll
+        for (int ct = 0; ct < TC; ct++) row[ct] = nb_row(c, k, ct, t);
 #pragma unroll
         for (int ks = 0; ks < NRI * 2; ks++) {
             bf16x8 b[TC];
 #pragma unroll
-            for (int ct = 0; ct < TC; ct++) {
-                const int row = TAPS == 9 ? k.nb[ct][t] : k.col[ct];
-                b[ct] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(act + row * RS + (16 * ks + 8 * c.h) * 2));
-            }
+            for (int ct = 0; ct < TC; ct++)
+                b[ct] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(act + row[ct] * RS + (16 * ks + 8 * c.h) * 2));
 #pragma unroll
             for (int ro = 0; ro < NRO; ro++) {
                 bf16x8 a = ring.get(fi++);
@@ -319,6 +353,7 @@ __device__ __forceinline__ void conv_ldsfed(const Ctx& c, const Cols& k, Ring& r
                 for (int ct = 0; ct < TC; ct++) out[ro][ct] = MFMA(a, b[ct], out[ro][ct]);
             }
         }
+    }
 }
 
 template <int NR>
@@ -331,62 +366,544 @@ __device__ __forceinline__ void zero_acc(f32x16 (&a)[NR][TC]) {
             for (int i = 0; i < 16; i++) a[r][ct][i] = 0.f;
 }
 
-// BottleneckResidualBlock: x + c4(relu(LN(c3(relu(LN(c2(relu(LN(c1(relu(LN(x))))))))))))
+// Two-deep register ring of gamma/beta chunks (one chunk = the 8 x 16-byte loads of one LayerNorm row
+// tile for both column tiles).  Chunk j+2 is requested the moment chunk j has been consumed and pinned
+// there, so that by the time it is needed at least a row tile's worth of weight fragments have been
+// requested after it and the wait for it is a counted vmcnt, never a drain of the weight ring.
+// Chunk order of a bottleneck block: LN1 rt 0..NRC-1, LN2 rt 0..NRB-1, LN3 .., LN4 ..
 template <int C, int CB>
-__device__ __forceinline__ void bottleneck(const Ctx& c, const Cols& k, Ring& ring, const u32x4* gb,
-                                           f32x16 (&X)[C / 32][TC]) {
-    constexpr int NRC = C / 32, NRB = CB / 32;
-    const long long s1 = (long long)c.HW * (C / 4), sb = (long long)c.HW * (CB / 4);
-    int fi = 0;
-    f32x16 a1[NRB][TC], a2[NRB][TC];
-    zero_acc<NRB>(a1);
-    conv1x1_regfed<NRC, NRB>(c, k, ring, fi, gb, X, a1);
-    zero_acc<NRB>(a2);
-    conv_ldsfed<NRB, NRB, 9>(c, k, ring, fi, gb + s1, a1, a2);
-    zero_acc<NRB>(a1);
-    conv_ldsfed<NRB, NRB, 9>(c, k, ring, fi, gb + s1 + sb, a2, a1);
-    conv1x1_regfed<NRB, NRC>(c, k, ring, fi, gb + s1 + 2 * sb, a1, X);
-    ring.advance(fi);  // 2*NRC*NRB*2 + 2*9*2*NRB*NRB fragments: a multiple of RING for the supported shapes
-}
-
-// BroadcastResidualBlock: x + c2(relu(LN(bcast(relu(LN(c1(relu(LN(x)))))))))
-template <int C>
-__device__ __forceinline__ void broadcast_block(const Ctx& c, const Cols& k, Ring& ring, const u32x4* gb,
-                                                const u32x4* wbf, const float* bb, f32x16 (&X)[C / 32][TC]) {
-    constexpr int NRC = C / 32;
-    constexpr int RS = C * 2 + 16;
-    const long long s1 = (long long)c.HW * (C / 4);
-    const int KP = c.L.kp, QT = c.L.qt, TBS = c.L.tbs;
-    char* tb = c.smem + c.L.tb_off;
-    char* act = c.smem + c.L.act_off;
-    int fi = 0;
-    {
-        f32x16 a1[NRC][TC];
-        zero_acc<NRC>(a1);
-        conv1x1_regfed<NRC, NRC>(c, k, ring, fi, gb, X, a1);
-        // LN2 + ReLU -> bf16 -> transposed image TB[channel][board*KP + cell]
-        float mean[TC], rstd[TC];
-        ln_stats<NRC>(c, k, a1, C, mean, rstd);
-        for (int i = threadIdx.x; i < C * c.NB * (KP - c.HW); i += NT) {  // zero the K padding of every board
-            const int padw = KP - c.HW;
-            const int ch = i / (c.NB * padw), rem = i - ch * (c.NB * padw);
-            const int bd = rem / padw, pp = rem - bd * padw;
-            *reinterpret_cast<__bf16*>(tb + ch * TBS + (bd * KP + c.HW + pp) * 2) = (__bf16)0.f;
-        }
+struct GRing {
+    static constexpr int NRC = C / 32, NRB = CB / 32, NCH = NRC + 3 * NRB;
+    u32x4 g[2][TC][4];
+    unsigned offC[TC], offB[TC];  // per-lane byte offsets (p * cn4 + h) * 16 for cn4 = C/4 and CB/4
+    __device__ __forceinline__ void init(const Ctx& c, const Cols& k) {
 #pragma unroll
-        for (int rt = 0; rt < NRC; rt++) {
-            u32x4 g[TC][4];
-            gb_load(gb + s1, C / 4, c, k, rt, g);
+        for (int ct = 0; ct < TC; ct++) {
+            offC[ct] = (unsigned)(k.p[ct] * (C / 4) + c.h) * 16u;
+            offB[ct] = (unsigned)(k.p[ct] * (CB / 4) + c.h) * 16u;
+        }
+    }
+    // chunk j (0 <= j < 2*NCH; j >= NCH addresses the NEXT block) into slot j % 2
+    __device__ __forceinline__ void load(int j, const char* gbb, const char* gbn, int HW) {
+        const char* base = j >= NCH ? gbn : gbb;
+        const int jj = j >= NCH ? j - NCH : j;
+        const bool wide = jj < NRC;
+        const int ln = wide ? 0 : 1 + (jj - NRC) / NRB;      // which LayerNorm of the block
+        const int rt = wide ? jj : (jj - NRC) % NRB;
+        const size_t sec = wide ? 0 : ((size_t)HW * (C / 4) + (size_t)(ln - 1) * HW * (CB / 4)) * 16;
+#pragma unroll
+        for (int ct = 0; ct < TC; ct++)
+#pragma unroll
+            for (int qd = 0; qd < 4; qd++)
+                g[j % 2][ct][qd] = *reinterpret_cast<const u32x4*>(base + sec + (wide ? offC[ct] : offB[ct]) +
+                                                                   (8 * rt + 2 * qd) * 16);
+        __builtin_amdgcn_sched_barrier(0x38F);
+    }
+};
+
+// BottleneckResidualBlock: x + c4(relu(LN(c3(relu(LN(c2(relu(LN(c1(relu(LN(x))))))))))))
+// On entry the gamma/beta ring holds chunks 0 and 1 of this block; on exit chunks 0 and 1 of the next.
+template <int C, int CB>
+__device__ __forceinline__ void bottleneck(const Ctx& c, const Cols& k, Ring& ring, GRing<C, CB>& gr, const char* gbb,
+                                           const char* gbn, f32x16 (&X)[C / 32][TC]) {
+    constexpr int NRC = C / 32, NRB = CB / 32;
+    constexpr int RS = CB * 2 + 16;
+    char* act = c.smem + c.L.act_off;
+    int fi = 0, gj = 0;
+    float mean[TC], rstd[TC];
+    f32x16 a1[NRB][TC], a2[NRB][TC];
+
+    // ---- LN1 + c1 (C -> CB), B operand straight from X ----
+    ln_stats<NRC>(c, k, X, C, mean, rstd);
+    zero_acc<NRB>(a1);
+#pragma unroll
+    for (int rt = 0; rt < NRC; rt++) {
+        bf16x8 bf[TC][2];
+#pragma unroll
+        for (int ct = 0; ct < TC; ct++) {
+            float y[16];
+            ln_apply(X[rt][ct], mean[ct], rstd[ct], gr.g[gj % 2][ct], y);
+            bf[ct][0] = pack8(&y[0]);
+            bf[ct][1] = pack8(&y[8]);
+        }
+        gr.load(gj + 2, gbb, gbn, c.HW);
+        gj++;
+#pragma unroll
+        for (int s = 0; s < 2; s++)
+#pragma unroll
+            for (int ro = 0; ro < NRB; ro++) {
+                bf16x8 a = ring.get(fi++);
+#pragma unroll
+                for (int ct = 0; ct < TC; ct++) a1[ro][ct] = MFMA(a, bf[ct][s], a1[ro][ct]);
+            }
+    }
+    // ---- LN2 -> image -> c2 (3x3), LN3 -> image -> c3 (3x3) ----
+#pragma unroll
+    for (int layer = 0; layer < 2; layer++) {
+        f32x16 (&in)[NRB][TC] = layer == 0 ? a1 : a2;
+        f32x16 (&out)[NRB][TC] = layer == 0 ? a2 : a1;
+        ln_stats<NRB>(c, k, in, CB, mean, rstd);
+#pragma unroll
+        for (int rt = 0; rt < NRB; rt++) {
 #pragma unroll
             for (int ct = 0; ct < TC; ct++) {
                 float y[16];
-                ln_apply(a1[rt][ct], mean[ct], rstd[ct], g[ct], y);
-                if (k.valid[ct]) {
-                    const int cbase = k.board[ct] * KP + k.p[ct];
+                ln_apply(in[rt][ct], mean[ct], rstd[ct], gr.g[gj % 2][ct], y);
+                if (!k.valid[ct]) {
 #pragma unroll
-                    for (int i = 0; i < 16; i++) {
-                        const int ch = 32 * rt + (i & 3) + 8 * (i >> 2) + 4 * c.h;
-                        *reinterpret_cast<__bf16*>(tb + ch * TBS + cbase * 2) = (__bf16)y[i];
+                    for (int i = 0; i < 16; i++) y[i] = 0.f;
+                }
+                act_store(act, RS, k.col[ct], rt, c.h, y);
+            }
+            gr.load(gj + 2, gbb, gbn, c.HW);
+            gj++;
+        }
+        lds_barrier();
+        zero_acc<NRB>(out);
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
+            int row[TC];
+#pragma unroll
+            for (int ct = 0; ct < TC; ct++) row[ct] = nb_row(c, k, ct, t);
+#pragma unroll
+            for (int ks = 0; ks < NRB * 2; ks++) {
+                bf16x8 b[TC];
+#pragma unroll
+                for (int ct = 0; ct < TC; ct++)
+                    b[ct] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(act + row[ct] * RS + (16 * ks + 8 * c.h) * 2));
+#pragma unroll
+                for (int ro = 0; ro < NRB; ro++) {
+                    bf16x8 a = ring.get(fi++);
+#pragma unroll
+                    for (int ct = 0; ct < TC; ct++) out[ro][ct] = MFMA(a, b[ct], out[ro][ct]);
+                }
+            }
+        }
+    }
+    // ---- LN4 + c4 (CB -> C) accumulated into X ----
+    ln_stats<NRB>(c, k, a1, CB, mean, rstd);
+#pragma unroll
+    for (int rt = 0; rt < NRB; rt++) {
+        bf16x8 bf[TC][2];
+#pragma unroll
+        for (int ct = 0; ct < TC; ct++) {
+            float y[16];
+            ln_apply(a1[rt][ct], mean[ct], rstd[ct], gr.g[gj % 2][ct], y);
+            bf[ct][0] = pack8(&y[0]);
+            bf[ct][1] = pack8(&y[8]);
+        }
+        gr.load(gj + 2, gbb, gbn, c.HW);
+        gj++;
+#pragma unroll
+        for (int s = 0; s < 2; s++)
+#pragma unroll
+            for (int ro = 0; ro < NRC; ro++) {
+                bf16x8 a = ring.get(fi++);
+#pragma unroll
+                for (int ct = 0; ct < TC; ct++) X[ro][ct] = MFMA(a, bf[ct][s], X[ro][ct]);
+            }
+    }
+    ring.advance(fi);  // 4*NRC*NRB + 36*NRB*NRB fragments: a multiple of RING for the supported shapes
+}
+
+// ---- shared prologue: per-board meta data and per-lane column info -----------------------------
+template <int IN>
+__device__ __forceinline__ bool setup(const NetDims& d, const NetIO& io, int NB, Ctx& c, Cols& k) {
+    const int tid = threadIdx.x;
+    const int g0 = blockIdx.x * NB;
+    if (tid < MAXNB) {
+        const int g = g0 + tid;
+        const bool ok = tid < NB && g < io.B && (!io.active || io.active[g]);
+        c.meta[tid] = (ok && IN == IN_HIDDEN) ? io.src_slot[g] : 0;
+        c.meta[MAXNB + tid] = ok ? io.dst_slot[g] : 0;
+        c.meta[2 * MAXNB + tid] = ok ? 1 : 0;
+        c.meta[3 * MAXNB + tid] = (ok && IN == IN_HIDDEN) ? io.action_cells[io.action[g]] : -1;
+    }
+    lds_barrier();
+    int any = 0;
+    for (int b = 0; b < NB; b++) any |= c.meta[2 * MAXNB + b];
+    if (!any) return false;
+#pragma unroll
+    for (int ct = 0; ct < TC; ct++) {
+        const int col = 64 * c.wave + 32 * ct + c.r;
+        k.col[ct] = col;
+        k.valid[ct] = col < NB * d.HW;
+        k.board[ct] = k.valid[ct] ? col / d.HW : MAXNB;
+        k.p[ct] = k.valid[ct] ? col - k.board[ct] * d.HW : 0;
+        k.live[ct] = k.valid[ct] && c.meta[2 * MAXNB + k.board[ct]];
+        unsigned m = 0;
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
+            const int y = k.p[ct] / d.Wd + t / 3 - 1, x = k.p[ct] % d.Wd + t % 3 - 1;
+            if (k.valid[ct] && y >= 0 && y < d.H && x >= 0 && x < d.Wd) m |= 1u << t;
+        }
+        k.nbmask[ct] = m;
+    }
+    return true;
+}
+
+__device__ __forceinline__ void ctx_init(Ctx& c, char* smem, const LdsPlan& L, const NetDims& d, int NB) {
+    const int tid = threadIdx.x;
+    c.smem = smem;
+    c.L = L;
+    c.HW = d.HW;
+    c.NB = NB;
+    c.Wd = d.Wd;
+    c.lane = tid & 63;
+    c.wave = tid >> 6;
+    c.h = c.lane >> 5;
+    c.r = c.lane & 31;
+    c.colsum = reinterpret_cast<float*>(smem + L.colsum_off);
+    c.bstat = reinterpret_cast<float*>(smem + L.bstat_off);
+    c.meta = reinterpret_cast<int*>(smem + L.meta_off);
+}
+
+// X <-> [slot][C][HW] fp32 in the hidden-state pool (slot index from meta row `which`).
+template <int NRC>
+__device__ __forceinline__ void x_load(const Ctx& c, const Cols& k, const float* pool, int which, int C,
+                                       f32x16 (&X)[NRC][TC]) {
+#pragma unroll
+    for (int ct = 0; ct < TC; ct++) {
+        const int bd = k.valid[ct] ? k.board[ct] : 0;
+        const float* src = pool + (long long)c.meta[which * MAXNB + bd] * C * c.HW + k.p[ct];
+#pragma unroll
+        for (int rt = 0; rt < NRC; rt++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int ch = 32 * rt + (i & 3) + 8 * (i >> 2) + 4 * c.h;
+                X[rt][ct][i] = k.live[ct] ? src[(long long)ch * c.HW] : 0.f;
+            }
+    }
+}
+template <int NRC>
+__device__ __forceinline__ void x_store(const Ctx& c, const Cols& k, float* pool, int C, const f32x16 (&X)[NRC][TC]) {
+#pragma unroll
+    for (int ct = 0; ct < TC; ct++) {
+        if (!k.live[ct]) continue;
+        float* dst = pool + (long long)c.meta[MAXNB + k.board[ct]] * C * c.HW + k.p[ct];
+#pragma unroll
+        for (int rt = 0; rt < NRC; rt++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) dst[(long long)(32 * rt + (i & 3) + 8 * (i >> 2) + 4 * c.h) * c.HW] = X[rt][ct][i];
+    }
+}
+
+// ---- [conv0] + bottleneck blocks b0..b1-1 + [rescale, heads] -----------------------------------
+template <int C, int CB, int IN, int OUT>
+__global__ __launch_bounds__(NT, 1) void k_seg(NetDims d, TowerDev tw, HeadDev hd, NetIO io, LdsPlan L, int NB, int b0,
+                                               int b1) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NRC = C / 32;
+    constexpr int CIN0 = IN == IN_OBS ? 32 : C + 16;  // input channels of conv0, padded to 16
+    constexpr int KS0 = CIN0 / 16;
+    constexpr int KS0P = (KS0 * NRC + RING - 1) / RING * RING / NRC;  // k-steps per tap in the stream (padded)
+    constexpr int RS0 = CIN0 * 2 + 16;
+    constexpr int RSB = CB * 2 + 16;
+    static_assert((KS0P * NRC) % RING == 0, "conv0 fragment count per tap must be a multiple of RING");
+    const int tid = threadIdx.x;
+    Ctx c;
+    ctx_init(c, smem, L, d, NB);
+    Cols k;
+    if (!setup<IN>(d, io, NB, c, k)) return;
+    const int HW = d.HW, A = d.A;
+    const int g0 = blockIdx.x * NB;
+    char* act = smem + L.act_off;
+
+    Ring ring;
+    f32x16 X[NRC][TC];
+    if (IN == IN_X) {
+        ring.init(tw.stream + (long long)tw.foff[b0] * 64, c.lane);
+        x_load<NRC>(c, k, io.pool, 1, C, X);
+    } else {
+        ring.init(tw.stream, c.lane);
+        // ---------------- input image + conv0 ----------------
+        for (int i = tid; i < RS0 / 4; i += NT) reinterpret_cast<int*>(act + ZROW * RS0)[i] = 0;
+        if (IN == IN_OBS) {
+            zero_acc<NRC>(X);
+#pragma unroll
+            for (int ct = 0; ct < TC; ct++) {
+                const int g = g0 + (k.valid[ct] ? k.board[ct] : 0);
+                float y[16];
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const int ch = 16 * c.h + i;
+                    y[i] = (k.live[ct] && ch < d.O) ? io.obs[((long long)g * d.O + ch) * HW + k.p[ct]] : 0.f;
+                }
+                *reinterpret_cast<bf16x8*>(act + k.col[ct] * RS0 + (16 * c.h) * 2) = pack8(&y[0]);
+                *reinterpret_cast<bf16x8*>(act + k.col[ct] * RS0 + (16 * c.h + 8) * 2) = pack8(&y[8]);
+            }
+        } else {
+            x_load<NRC>(c, k, io.pool, 0, C, X);   // StartResidualBlock: X starts as the parent state s
+#pragma unroll
+            for (int ct = 0; ct < TC; ct++) {
+#pragma unroll
+                for (int rt = 0; rt < NRC; rt++) {
+                    float y[16];
+#pragma unroll
+                    for (int i = 0; i < 16; i++) y[i] = X[rt][ct][i];
+                    act_store(act, RS0, k.col[ct], rt, c.h, y);
+                }
+                // ConcatInputsBlock: the one-hot action planes as channels C .. C+a-1 (padded to 16)
+                if (c.h == ct) {
+                    float y[16];
+                    const int cell = c.meta[3 * MAXNB + (k.valid[ct] ? k.board[ct] : 0)];
+#pragma unroll
+                    for (int i = 0; i < 16; i++) y[i] = (k.live[ct] && i < d.a && cell == i * HW + k.p[ct]) ? 1.f : 0.f;
+                    *reinterpret_cast<bf16x8*>(act + k.col[ct] * RS0 + C * 2) = pack8(&y[0]);
+                    *reinterpret_cast<bf16x8*>(act + k.col[ct] * RS0 + (C + 8) * 2) = pack8(&y[8]);
+                }
+            }
+        }
+        lds_barrier();
+        for (int t = 0; t < 9; t++) {
+            int row[TC];
+#pragma unroll
+            for (int ct = 0; ct < TC; ct++) row[ct] = nb_row(c, k, ct, t);
+#pragma unroll
+            for (int ks = 0; ks < KS0; ks++) {
+                bf16x8 b[TC];
+#pragma unroll
+                for (int ct = 0; ct < TC; ct++)
+                    b[ct] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(act + row[ct] * RS0 + (16 * ks + 8 * c.h) * 2));
+#pragma unroll
+                for (int ro = 0; ro < NRC; ro++) {
+                    bf16x8 a = ring.get(ks * NRC + ro);
+#pragma unroll
+                    for (int ct = 0; ct < TC; ct++) X[ro][ct] = MFMA(a, b[ct], X[ro][ct]);
+                }
+            }
+#pragma unroll
+            for (int i = KS0 * NRC; i < KS0P * NRC; i++) (void)ring.get(i);  // padding fragments of the stream
+            ring.advance(KS0P * NRC);
+        }
+        lds_barrier();
+    }
+    // zero row of the tower's act image
+    for (int i = tid; i < RSB / 4; i += NT) reinterpret_cast<int*>(act + ZROW * RSB)[i] = 0;
+    lds_barrier();
+
+    if (b0 < b1) {
+        GRing<C, CB> gr;
+        gr.init(c, k);
+        const char* gbase = reinterpret_cast<const char*>(tw.gb);
+        gr.load(0, gbase + tw.gboff[b0] * 16, nullptr, HW);
+        gr.load(1, gbase + tw.gboff[b0] * 16, nullptr, HW);
+        for (int blk = b0; blk < b1; blk++) {
+            // the chunks requested past the end of the last block are never used: point them at valid memory
+            const int nxt = (blk + 1 < b1) ? blk + 1 : blk;
+            bottleneck<C, CB>(c, k, ring, gr, gbase + tw.gboff[blk] * 16, gbase + tw.gboff[nxt] * 16, X);
+        }
+    }
+
+    if (OUT == OUT_X) {
+        x_store<NRC>(c, k, io.pool, C, X);
+        return;
+    }
+    // ---------------- RescaleBlockExt + hidden-state store ----------------
+    {
+        float mn[TC], mx[TC];
+#pragma unroll
+        for (int ct = 0; ct < TC; ct++) {
+            float a = INFINITY, b = -INFINITY;
+#pragma unroll
+            for (int rt = 0; rt < NRC; rt++)
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    a = fminf(a, X[rt][ct][i]);
+                    b = fmaxf(b, X[rt][ct][i]);
+                }
+            mn[ct] = k.valid[ct] ? a : INFINITY;
+            mx[ct] = k.valid[ct] ? b : -INFINITY;
+        }
+        board_reduce<1>(c, k, mn, mx, 0.f);
+#pragma unroll
+        for (int ct = 0; ct < TC; ct++) {
+            const float dd = fmaxf(mx[ct] - mn[ct], 1e-5f);
+#pragma unroll
+            for (int rt = 0; rt < NRC; rt++)
+#pragma unroll
+                for (int i = 0; i < 16; i++) X[rt][ct][i] = (X[rt][ct][i] - mn[ct]) / dd;
+        }
+        x_store<NRC>(c, k, io.pool, C, X);
+    }
+    // ---------------- PredictionBlock ----------------
+    // 1x1 convs C -> {policy 0, policy 1, value} in fp32 on the VALU (3 output rows only): the per-board
+    // LayerNorm over a single 81-value channel that follows amplifies bf16 rounding, so these stay exact.
+    float* hs = reinterpret_cast<float*>(smem + L.head_off);
+    float* pfeat = hs;                         // [NB][2*HW]
+    float* vfeat = pfeat + MAXNB * 2 * HW;     // [NB][HW]
+    float* lgt = vfeat + MAXNB * HW;           // [NB][A]
+    float* hv = lgt + MAXNB * A;               // [NB][C]
+    float* hwl = hv + MAXNB * C;               // [3][C] head conv weights
+    for (int i = tid; i < 3 * C; i += NT) hwl[i] = hd.hconv[i];
+    lds_barrier();
+    float hp0[TC], hp1[TC], hvv[TC];
+#pragma unroll
+    for (int ct = 0; ct < TC; ct++) {
+        float p0 = 0.f, p1 = 0.f, v = 0.f;
+#pragma unroll
+        for (int rt = 0; rt < NRC; rt++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int ch = 32 * rt + (i & 3) + 8 * (i >> 2) + 4 * c.h;
+                const float x = X[rt][ct][i];
+                p0 = fmaf(x, hwl[ch], p0);
+                p1 = fmaf(x, hwl[C + ch], p1);
+                v = fmaf(x, hwl[2 * C + ch], v);
+            }
+        hp0[ct] = p0 + __shfl_xor(p0, 32);
+        hp1[ct] = p1 + __shfl_xor(p1, 32);
+        hvv[ct] = v + __shfl_xor(v, 32);
+    }
+    {
+        // policy LN over (2, HW), value LN over (1, HW)
+        float s[TC], q[TC], vs[TC], vq[TC];
+#pragma unroll
+        for (int ct = 0; ct < TC; ct++) {
+            const bool own = k.valid[ct] && c.h == 0;
+            s[ct] = own ? hp0[ct] + hp1[ct] : 0.f;
+            q[ct] = own ? hp0[ct] * hp0[ct] + hp1[ct] * hp1[ct] : 0.f;
+            vs[ct] = own ? hvv[ct] : 0.f;
+            vq[ct] = own ? hvv[ct] * hvv[ct] : 0.f;
+        }
+        board_reduce<0>(c, k, s, q, 1.0f / (float)(2 * HW));
+        board_reduce<0>(c, k, vs, vq, 1.0f / (float)HW);
+#pragma unroll
+        for (int ct = 0; ct < TC; ct++) {
+            if (k.valid[ct] && c.h == 0) {
+                const int bd = k.board[ct], p = k.p[ct];
+                float t0 = (hp0[ct] - s[ct]) * q[ct] * hd.plng[p] + hd.plnb[p];
+                float t1 = (hp1[ct] - s[ct]) * q[ct] * hd.plng[HW + p] + hd.plnb[HW + p];
+                pfeat[bd * 2 * HW + p] = fmaxf(t0, 0.f);
+                pfeat[bd * 2 * HW + HW + p] = fmaxf(t1, 0.f);
+                float t = (hvv[ct] - vs[ct]) * vq[ct] * hd.vlng[p] + hd.vlnb[p];
+                vfeat[bd * HW + p] = fmaxf(t, 0.f);
+            }
+        }
+    }
+    lds_barrier();
+    for (int idx = tid; idx < NB * A; idx += NT) {
+        const int bd = idx / A, a = idx - bd * A;
+        float acc = hd.pfcb[a];
+        const float* f = pfeat + bd * 2 * HW;
+        for (int i = 0; i < 2 * HW; i++) acc = fmaf(f[i], hd.pfcw[(long long)i * A + a], acc);
+        lgt[idx] = acc;
+    }
+    for (int idx = tid; idx < NB * C; idx += NT) {
+        const int bd = idx / C, ch = idx - bd * C;
+        float acc = hd.vfc1b[ch];
+        const float* f = vfeat + bd * HW;
+        for (int p = 0; p < HW; p++) acc = fmaf(f[p], hd.vfc1w[(long long)p * C + ch], acc);
+        hv[idx] = fmaxf(acc, 0.f);
+    }
+    lds_barrier();
+    for (int bd = c.wave; bd < NB; bd += 4) {
+        if (!c.meta[2 * MAXNB + bd]) continue;
+        const int g = g0 + bd;
+        float part = 0.f;
+        for (int ch = c.lane; ch < C; ch += 64) part = fmaf(hv[bd * C + ch], hd.vfc2w[ch], part);
+        float mx = -INFINITY;
+        for (int a = c.lane; a < A; a += 64) mx = fmaxf(mx, lgt[bd * A + a]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            part += __shfl_xor(part, o);
+            mx = fmaxf(mx, __shfl_xor(mx, o));
+        }
+        float se = 0.f;
+        for (int a = c.lane; a < A; a += 64) se += expf(lgt[bd * A + a] - mx);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o);
+        for (int a = c.lane; a < A; a += 64) {
+            const float l = lgt[bd * A + a];
+            io.logits[(long long)g * A + a] = l;
+            io.policy[(long long)g * A + a] = expf(l - mx) / se;
+        }
+        if (c.lane == 0) {
+            float v = part + hd.vfc2b[0];
+            if (d.two_players) v = tanhf(v);
+            io.value[g] = d.value_scale * (double)v;
+        }
+    }
+}
+
+// ---- BroadcastResidualBlock: x + c2(relu(LN(bcast(relu(LN(c1(relu(LN(x))))))))) ------------------
+template <int C>
+__global__ __launch_bounds__(NT, 1) void k_bcast(NetDims d, TowerDev tw, NetIO io, LdsPlan L, int NB, int blk) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NRC = C / 32;
+    constexpr int NH = NRC / 2;
+    constexpr int RS = C * 2 + 16;
+    Ctx c;
+    ctx_init(c, smem, L, d, NB);
+    Cols k;
+    if (!setup<IN_X>(d, io, NB, c, k)) return;
+    const u32x4* gb = tw.gb + tw.gboff[blk];
+    const u32x4* wbf = tw.wbf + tw.wboff[blk];
+    const float* bb = tw.bb + tw.bboff[blk];
+    const long long s1 = (long long)c.HW * (C / 4);
+    const int KP = L.kp, QT = L.qt, TBS = L.tbs;
+    char* tb = smem + L.tb_off;
+    char* act = smem + L.act_off;
+    Ring ring;
+    ring.init(tw.stream + (long long)tw.foff[blk] * 64, c.lane);
+    f32x16 X[NRC][TC];
+    x_load<NRC>(c, k, io.pool, 1, C, X);
+    int fi = 0;
+    {
+        // c1 (C -> C) is computed in two halves of C/2 output channels, TWICE: once for the LN2 statistics
+        // and once more to normalise (keeping all C output rows next to X costs 128 more accumulators).
+        // The stream holds c1's fragments twice, in this order.
+        float m1[TC], r1[TC];
+        ln_stats<NRC>(c, k, X, C, m1, r1);
+        float mean[TC], rstd[TC];
+#pragma unroll
+        for (int ct = 0; ct < TC; ct++) mean[ct] = rstd[ct] = 0.f;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            f32x16 ah[NH][TC];
+            zero_acc<NH>(ah);
+            conv1x1_regfed_core<NRC, NH>(c, k, ring, fi, gb, X, ah, m1, r1);
+#pragma unroll
+            for (int ct = 0; ct < TC; ct++)
+                if (k.valid[ct]) {
+#pragma unroll
+                    for (int rt = 0; rt < NH; rt++)
+#pragma unroll
+                        for (int i = 0; i < 16; i++) {
+                            const float x = ah[rt][ct][i];
+                            mean[ct] += x;
+                            rstd[ct] = fmaf(x, x, rstd[ct]);
+                        }
+                }
+        }
+        board_reduce<0>(c, k, mean, rstd, 1.0f / (float)(C * c.HW));
+        for (int i = threadIdx.x; i < C * NB * (KP - c.HW); i += NT) {  // zero the K padding of every board
+            const int padw = KP - c.HW;
+            const int ch = i / (NB * padw), rem = i - ch * (NB * padw);
+            const int bd = rem / padw, pp = rem - bd * padw;
+            *reinterpret_cast<__bf16*>(tb + ch * TBS + (bd * KP + c.HW + pp) * 2) = (__bf16)0.f;
+        }
+        // LN2 + ReLU -> bf16 -> transposed image TB[channel][board*KP + cell]
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            f32x16 ah[NH][TC];
+            zero_acc<NH>(ah);
+            conv1x1_regfed_core<NRC, NH>(c, k, ring, fi, gb, X, ah, m1, r1);
+#pragma unroll
+            for (int rt = 0; rt < NH; rt++) {
+                u32x4 g[TC][4];
+                gb_load(gb + s1, C / 4, c, k, half * NH + rt, g);
+#pragma unroll
+                for (int ct = 0; ct < TC; ct++) {
+                    float y[16];
+                    ln_apply(ah[rt][ct], mean[ct], rstd[ct], g[ct], y);
+                    if (k.valid[ct]) {
+                        const int cbase = k.board[ct] * KP + k.p[ct];
+#pragma unroll
+                        for (int i = 0; i < 16; i++) {
+                            const int ch = 32 * (half * NH + rt) + (i & 3) + 8 * (i >> 2) + 4 * c.h;
+                            *reinterpret_cast<__bf16*>(tb + ch * TBS + cbase * 2) = (__bf16)y[i];
+                        }
                     }
                 }
             }
@@ -398,7 +915,7 @@ __device__ __forceinline__ void broadcast_block(const Ctx& c, const Cols& k, Rin
     float* wpart = c.bstat + 2 * (MAXNB + 1);  // [4 waves][MAXNB][2]
     float bmean = 0.f, brstd = 0.f;
     for (int pass = 0; pass < 2; pass++) {
-        for (int bd = 0; bd < c.NB; bd++) {
+        for (int bd = 0; bd < NB; bd++) {
             float ps = 0.f, pq = 0.f;
             if (pass == 1) {
                 bmean = c.bstat[2 * bd];
@@ -453,7 +970,7 @@ __device__ __forceinline__ void broadcast_block(const Ctx& c, const Cols& k, Rin
         }
         if (pass == 0) {
             lds_barrier();
-            if ((int)threadIdx.x < c.NB) {
+            if ((int)threadIdx.x < NB) {
                 const int bd = threadIdx.x;
                 float s = 0.f, q = 0.f;
                 for (int w = 0; w < 4; w++) {
@@ -484,303 +1001,7 @@ __device__ __forceinline__ void broadcast_block(const Ctx& c, const Cols& k, Rin
             for (int ct = 0; ct < TC; ct++) X[ro][ct] = MFMA(a, b[ct], X[ro][ct]);
         }
     }
-    ring.advance(fi);
-    lds_barrier();
-}
-
-template <int C, int CB, bool INITIAL>
-__global__ __launch_bounds__(NT, 1) void k_net_mfma(NetDims d, TowerDev tw, HeadDev hd, NetIO io, LdsPlan L, int NB) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NRC = C / 32;
-    constexpr int CIN0 = INITIAL ? 32 : C + 16;     // input channels of conv0, padded to 16
-    constexpr int KS0 = CIN0 / 16;
-    constexpr int KS0P = (KS0 * NRC + RING - 1) / RING * RING / NRC;  // k-steps per tap in the stream (padded)
-    constexpr int RS0 = CIN0 * 2 + 16;
-    static_assert((KS0P * NRC) % RING == 0, "conv0 fragment count per tap must be a multiple of RING");
-    const int tid = threadIdx.x;
-    Ctx c;
-    c.smem = smem;
-    c.L = L;
-    c.HW = d.HW;
-    c.NB = NB;
-    c.lane = tid & 63;
-    c.wave = tid >> 6;
-    c.h = c.lane >> 5;
-    c.r = c.lane & 31;
-    c.colsum = reinterpret_cast<float*>(smem + L.colsum_off);
-    c.bstat = reinterpret_cast<float*>(smem + L.bstat_off);
-    int* meta = reinterpret_cast<int*>(smem + L.meta_off);  // [4][MAXNB]: src, dst, live, cell
-    short* nbt = reinterpret_cast<short*>(smem + L.nbt_off); // [9][COLS]
-    const int HW = d.HW, A = d.A;
-    const int g0 = blockIdx.x * NB;
-
-    if (tid < MAXNB) {
-        const int g = g0 + tid;
-        const bool ok = tid < NB && g < io.B && (!io.active || io.active[g]);
-        meta[tid] = (ok && !INITIAL) ? io.src_slot[g] : 0;
-        meta[MAXNB + tid] = ok ? io.dst_slot[g] : 0;
-        meta[2 * MAXNB + tid] = ok ? 1 : 0;
-        meta[3 * MAXNB + tid] = (ok && !INITIAL) ? io.action_cells[io.action[g]] : -1;
-    }
-    for (int i = tid; i < 9 * COLS; i += NT) {
-        const int t = i / COLS, col = i - t * COLS;
-        int row = ZROW;
-        if (col < NB * HW) {
-            const int bd = col / HW, p = col - bd * HW;
-            const int y = p / d.Wd + t / 3 - 1, x = p % d.Wd + t % 3 - 1;
-            if (y >= 0 && y < d.H && x >= 0 && x < d.Wd) row = bd * HW + y * d.Wd + x;
-        }
-        nbt[i] = (short)row;
-    }
-    lds_barrier();
-    {
-        int any = 0;
-        for (int b = 0; b < NB; b++) any |= meta[2 * MAXNB + b];
-        if (!any) return;
-    }
-    Cols k;
-#pragma unroll
-    for (int ct = 0; ct < TC; ct++) {
-        const int col = 64 * c.wave + 32 * ct + c.r;
-        k.col[ct] = col;
-        k.valid[ct] = col < NB * HW;
-        k.board[ct] = k.valid[ct] ? col / HW : MAXNB;
-        k.p[ct] = k.valid[ct] ? col - k.board[ct] * HW : 0;
-        k.live[ct] = k.valid[ct] && meta[2 * MAXNB + k.board[ct]];
-#pragma unroll
-        for (int t = 0; t < 9; t++) k.nb[ct][t] = nbt[t * COLS + col];
-    }
-
-    Ring ring;
-    ring.init(tw.stream, c.lane);
-
-    // ---------------- input image + conv0 ----------------
-    f32x16 X[NRC][TC];
-    char* act = smem + L.act_off;
-    for (int i = tid; i < RS0 / 4; i += NT) reinterpret_cast<int*>(act + ZROW * RS0)[i] = 0;
-    if (INITIAL) {
-        zero_acc<NRC>(X);
-#pragma unroll
-        for (int ct = 0; ct < TC; ct++) {
-            const int g = g0 + (k.valid[ct] ? k.board[ct] : 0);
-            float y[16];
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const int ch = 16 * c.h + i;
-                y[i] = (k.live[ct] && ch < d.O) ? io.obs[((long long)g * d.O + ch) * HW + k.p[ct]] : 0.f;
-            }
-            *reinterpret_cast<bf16x8*>(act + k.col[ct] * RS0 + (16 * c.h) * 2) = pack8(&y[0]);
-            *reinterpret_cast<bf16x8*>(act + k.col[ct] * RS0 + (16 * c.h + 8) * 2) = pack8(&y[8]);
-        }
-    } else {
-#pragma unroll
-        for (int ct = 0; ct < TC; ct++) {
-            const int bd = k.valid[ct] ? k.board[ct] : 0;
-            const float* src = io.pool + (long long)meta[bd] * C * HW + k.p[ct];
-#pragma unroll
-            for (int rt = 0; rt < NRC; rt++) {
-                float y[16];
-#pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    const int ch = 32 * rt + (i & 3) + 8 * (i >> 2) + 4 * c.h;
-                    y[i] = k.live[ct] ? src[(long long)ch * HW] : 0.f;
-                    X[rt][ct][i] = y[i];
-                }
-                act_store(act, RS0, k.col[ct], rt, c.h, y);
-            }
-            // ConcatInputsBlock: the one-hot action planes as channels C .. C+a-1 (padded to 16)
-            if (c.h == ct) {
-                float y[16];
-                const int cell = meta[3 * MAXNB + bd];
-#pragma unroll
-                for (int i = 0; i < 16; i++) y[i] = (k.live[ct] && i < d.a && cell == i * HW + k.p[ct]) ? 1.f : 0.f;
-                *reinterpret_cast<bf16x8*>(act + k.col[ct] * RS0 + C * 2) = pack8(&y[0]);
-                *reinterpret_cast<bf16x8*>(act + k.col[ct] * RS0 + (C + 8) * 2) = pack8(&y[8]);
-            }
-        }
-    }
-    lds_barrier();
-    for (int t = 0; t < 9; t++) {
-        int row[TC];
-#pragma unroll
-        for (int ct = 0; ct < TC; ct++) row[ct] = nbt[t * COLS + k.col[ct]];
-#pragma unroll
-        for (int ks = 0; ks < KS0; ks++) {
-            bf16x8 b[TC];
-#pragma unroll
-            for (int ct = 0; ct < TC; ct++)
-                b[ct] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(act + row[ct] * RS0 + (16 * ks + 8 * c.h) * 2));
-#pragma unroll
-            for (int ro = 0; ro < NRC; ro++) {
-                bf16x8 a = ring.get(ks * NRC + ro);
-#pragma unroll
-                for (int ct = 0; ct < TC; ct++) X[ro][ct] = MFMA(a, b[ct], X[ro][ct]);
-            }
-        }
-#pragma unroll
-        for (int i = KS0 * NRC; i < KS0P * NRC; i++) (void)ring.get(i);  // padding fragments of the stream
-        ring.advance(KS0P * NRC);
-    }
-    lds_barrier();
-    // the tower's act image uses a different row stride: re-zero its zero row
-    {
-        constexpr int RSB = CB * 2 + 16, RSC = C * 2 + 16;
-        for (int i = tid; i < RSC / 4; i += NT) {
-            if (i < RSB / 4) reinterpret_cast<int*>(act + ZROW * RSB)[i] = 0;
-            reinterpret_cast<int*>(act + ZROW * RSC)[i] = 0;
-        }
-    }
-    lds_barrier();
-
-    // ---------------- residual tower ----------------
-    for (int blk = 0; blk < d.R; blk++) {
-        const u32x4* gb = tw.gb + tw.gboff[blk];
-        if (tw.type[blk] == 0) bottleneck<C, CB>(c, k, ring, gb, X);
-        else {
-            broadcast_block<C>(c, k, ring, gb, tw.wbf + tw.wboff[blk], tw.bb + tw.bboff[blk], X);
-            constexpr int RSB = CB * 2 + 16;
-            for (int i = tid; i < RSB / 4; i += NT) reinterpret_cast<int*>(act + ZROW * RSB)[i] = 0;
-            lds_barrier();
-        }
-    }
-
-    // ---------------- RescaleBlockExt + hidden-state store ----------------
-    {
-        float mn[TC], mx[TC];
-#pragma unroll
-        for (int ct = 0; ct < TC; ct++) {
-            float a = INFINITY, b = -INFINITY;
-#pragma unroll
-            for (int rt = 0; rt < NRC; rt++)
-#pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    a = fminf(a, X[rt][ct][i]);
-                    b = fmaxf(b, X[rt][ct][i]);
-                }
-            mn[ct] = k.valid[ct] ? a : INFINITY;
-            mx[ct] = k.valid[ct] ? b : -INFINITY;
-        }
-        board_reduce<1>(c, k, mn, mx, 0.f);
-#pragma unroll
-        for (int ct = 0; ct < TC; ct++) {
-            const float dd = fmaxf(mx[ct] - mn[ct], 1e-5f);
-            const int bd = k.valid[ct] ? k.board[ct] : 0;
-            float* dst = io.pool + (long long)meta[MAXNB + bd] * C * HW + k.p[ct];
-#pragma unroll
-            for (int rt = 0; rt < NRC; rt++)
-#pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    const int ch = 32 * rt + (i & 3) + 8 * (i >> 2) + 4 * c.h;
-                    const float y = (X[rt][ct][i] - mn[ct]) / dd;
-                    X[rt][ct][i] = y;
-                    if (k.live[ct]) dst[(long long)ch * HW] = y;
-                }
-        }
-    }
-
-    // ---------------- PredictionBlock ----------------
-    // 1x1 convs C -> {policy 0, policy 1, value} in fp32 on the VALU (3 output rows only): the per-board
-    // LayerNorm over a single 81-value channel that follows amplifies bf16 rounding, so these stay exact.
-    float* hs = reinterpret_cast<float*>(smem + L.head_off);
-    float* pfeat = hs;                         // [NB][2*HW]
-    float* vfeat = pfeat + MAXNB * 2 * HW;     // [NB][HW]
-    float* lgt = vfeat + MAXNB * HW;           // [NB][A]
-    float* hv = lgt + MAXNB * A;               // [NB][C]
-    float* hwl = hv + MAXNB * C;               // [3][C] head conv weights
-    for (int i = tid; i < 3 * C; i += NT) hwl[i] = hd.hconv[i];
-    lds_barrier();
-    f32x16 hacc[TC];
-#pragma unroll
-    for (int ct = 0; ct < TC; ct++) {
-        float p0 = 0.f, p1 = 0.f, v = 0.f;
-#pragma unroll
-        for (int rt = 0; rt < NRC; rt++)
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const int ch = 32 * rt + (i & 3) + 8 * (i >> 2) + 4 * c.h;
-                const float x = X[rt][ct][i];
-                p0 = fmaf(x, hwl[ch], p0);
-                p1 = fmaf(x, hwl[C + ch], p1);
-                v = fmaf(x, hwl[2 * C + ch], v);
-            }
-        p0 += __shfl_xor(p0, 32);
-        p1 += __shfl_xor(p1, 32);
-        v += __shfl_xor(v, 32);
-        hacc[ct][0] = p0;
-        hacc[ct][1] = p1;
-        hacc[ct][2] = v;
-    }
-    {
-        // policy LN over (2, HW), value LN over (1, HW); rows 0..3 sit in regs 0..3 of lanes with h == 0
-        float s[TC], q[TC], vs[TC], vq[TC];
-#pragma unroll
-        for (int ct = 0; ct < TC; ct++) {
-            const bool own = k.valid[ct] && c.h == 0;
-            const float p0 = hacc[ct][0], p1 = hacc[ct][1], v = hacc[ct][2];
-            s[ct] = own ? p0 + p1 : 0.f;
-            q[ct] = own ? p0 * p0 + p1 * p1 : 0.f;
-            vs[ct] = own ? v : 0.f;
-            vq[ct] = own ? v * v : 0.f;
-        }
-        board_reduce<0>(c, k, s, q, 1.0f / (float)(2 * HW));
-        board_reduce<0>(c, k, vs, vq, 1.0f / (float)HW);
-#pragma unroll
-        for (int ct = 0; ct < TC; ct++) {
-            if (k.valid[ct] && c.h == 0) {
-                const int bd = k.board[ct], p = k.p[ct];
-#pragma unroll
-                for (int ch = 0; ch < 2; ch++) {
-                    float t = (hacc[ct][ch] - s[ct]) * q[ct] * hd.plng[ch * HW + p] + hd.plnb[ch * HW + p];
-                    pfeat[bd * 2 * HW + ch * HW + p] = fmaxf(t, 0.f);
-                }
-                float t = (hacc[ct][2] - vs[ct]) * vq[ct] * hd.vlng[p] + hd.vlnb[p];
-                vfeat[bd * HW + p] = fmaxf(t, 0.f);
-            }
-        }
-    }
-    lds_barrier();
-    for (int idx = tid; idx < NB * A; idx += NT) {
-        const int bd = idx / A, a = idx - bd * A;
-        float acc = hd.pfcb[a];
-        const float* f = pfeat + bd * 2 * HW;
-        for (int i = 0; i < 2 * HW; i++) acc = fmaf(f[i], hd.pfcw[(long long)i * A + a], acc);
-        lgt[idx] = acc;
-    }
-    for (int idx = tid; idx < NB * C; idx += NT) {
-        const int bd = idx / C, ch = idx - bd * C;
-        float acc = hd.vfc1b[ch];
-        const float* f = vfeat + bd * HW;
-        for (int p = 0; p < HW; p++) acc = fmaf(f[p], hd.vfc1w[(long long)p * C + ch], acc);
-        hv[idx] = fmaxf(acc, 0.f);
-    }
-    lds_barrier();
-    for (int bd = c.wave; bd < NB; bd += 4) {
-        if (!meta[2 * MAXNB + bd]) continue;
-        const int g = g0 + bd;
-        float part = 0.f;
-        for (int ch = c.lane; ch < C; ch += 64) part = fmaf(hv[bd * C + ch], hd.vfc2w[ch], part);
-        float mx = -INFINITY;
-        for (int a = c.lane; a < A; a += 64) mx = fmaxf(mx, lgt[bd * A + a]);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            part += __shfl_xor(part, o);
-            mx = fmaxf(mx, __shfl_xor(mx, o));
-        }
-        float se = 0.f;
-        for (int a = c.lane; a < A; a += 64) se += expf(lgt[bd * A + a] - mx);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o);
-        for (int a = c.lane; a < A; a += 64) {
-            const float l = lgt[bd * A + a];
-            io.logits[(long long)g * A + a] = l;
-            io.policy[(long long)g * A + a] = expf(l - mx) / se;
-        }
-        if (c.lane == 0) {
-            float v = part + hd.vfc2b[0];
-            if (d.two_players) v = tanhf(v);
-            io.value[g] = d.value_scale * (double)v;
-        }
-    }
+    x_store<NRC>(c, k, io.pool, C, X);
 }
 
 // ------------------------------- host side: packing -------------------------------------------
@@ -858,7 +1079,7 @@ struct TowerHost {
 struct MfmaNet {
     NetDims d{};
     int NB = 0;
-    LdsPlan L{};
+    LdsPlan Lseg{}, Lbc{};
     void* bufs[16] = {nullptr};
     int nbufs = 0;
     TowerDev tw[2]{};
@@ -870,19 +1091,7 @@ namespace {
 
 bool shape_supported(const NetDims& d) { return d.C == 128 && d.Cb == 64 && d.O <= 32 && d.a <= 16 && d.HW <= 81 + 15; }
 
-LdsPlan make_plan(const NetDims& d, int NB) {
-    LdsPlan L{};
-    const int C = d.C;
-    const int rs0 = (C + 16) * 2 + 16, rsc = C * 2 + 16;
-    L.kp = (d.HW + 15) / 16 * 16;
-    L.qt = (d.HW + 31) / 32;
-    L.tbs = (NB * L.kp + 8) * 2;
-    const int act_tower = (COLS + 1) * rsc;
-    const int act_conv0 = (COLS + 1) * rs0;
-    L.act_off = 0;
-    L.tb_off = (act_tower + 15) / 16 * 16;
-    int end = L.tb_off + C * L.tbs;
-    if (act_conv0 > end) end = act_conv0;
+void plan_tail(LdsPlan& L, int end) {
     end = (end + 15) / 16 * 16;
     L.colsum_off = end;
     end += COLS * 2 * 4;
@@ -890,12 +1099,31 @@ LdsPlan make_plan(const NetDims& d, int NB) {
     end += (2 * (MAXNB + 1) + 4 * MAXNB * 2) * 4;
     L.meta_off = end;
     end += 4 * MAXNB * 4;
-    L.nbt_off = end;
-    end += 9 * COLS * 2;
-    end = (end + 15) / 16 * 16;
-    // head scratch overlaps the (dead) act image
+    L.total = (end + 15) / 16 * 16;
+}
+
+// k_seg: act image (conv0 input image / bottleneck image / head scratch share offset 0)
+LdsPlan make_plan_seg(const NetDims& d) {
+    LdsPlan L{};
+    const int rs0 = (d.C + 16) * 2 + 16, rsb = d.Cb * 2 + 16;
+    int end = (COLS + 1) * (rs0 > rsb ? rs0 : rsb);
+    const int head_need = (MAXNB * (3 * d.HW + d.A + d.C) + 3 * d.C) * 4;
+    if (head_need > end) end = head_need;
+    L.act_off = 0;
     L.head_off = 0;
-    L.total = end;
+    plan_tail(L, end);
+    return L;
+}
+// k_bcast: act image with C channels + transposed image TB
+LdsPlan make_plan_bcast(const NetDims& d, int NB) {
+    LdsPlan L{};
+    const int rsc = d.C * 2 + 16;
+    L.kp = (d.HW + 15) / 16 * 16;
+    L.qt = (d.HW + 31) / 32;
+    L.tbs = (NB * L.kp + 8) * 2;
+    L.act_off = 0;
+    L.tb_off = ((COLS + 1) * rsc + 15) / 16 * 16;
+    plan_tail(L, L.tb_off + d.C * L.tbs);
     return L;
 }
 
@@ -930,9 +1158,9 @@ MfmaNet* mfma_create(const NetDims& d, int /*max_batch*/, std::string* err) {
     n->d = d;
     n->NB = COLS / d.HW;
     if (n->NB > MAXNB) n->NB = MAXNB;
-    n->L = make_plan(d, n->NB);
-    const size_t head_need = ((size_t)MAXNB * (3 * d.HW + d.A + d.C) + 3 * d.C) * 4;
-    if (n->L.total > 160 * 1024 || head_need > (size_t)n->L.colsum_off) {
+    n->Lseg = make_plan_seg(d);
+    n->Lbc = make_plan_bcast(d, n->NB);
+    if (n->Lseg.total > 160 * 1024 || n->Lbc.total > 160 * 1024) {
         if (err) *err = "LDS plan does not fit 160 KiB";
         delete n;
         return nullptr;
@@ -972,6 +1200,7 @@ int mfma_pack_weights(MfmaNet* n, const NetDims& d, const float* blob, size_t co
             const bool bc = d.bcast_every_n > 0 && (i % d.bcast_every_n == d.bcast_every_n - 1);
             T.dev.type[i] = bc ? 1 : 0;
             T.dev.gboff[i] = (long long)(T.gb.size() / 8);
+            T.dev.foff[i] = (int)(T.stream.size() / 512);
             if (!bc) {
                 const float *g1 = take((size_t)C * HW), *b1 = take((size_t)C * HW), *c1 = take((size_t)Cb * C);
                 const float *g2 = take((size_t)Cb * HW), *b2 = take((size_t)Cb * HW), *c2 = take((size_t)Cb * Cb * 9);
@@ -990,13 +1219,14 @@ int mfma_pack_weights(MfmaNet* n, const NetDims& d, const float* blob, size_t co
                 const float *g2 = take((size_t)C * HW), *b2 = take((size_t)C * HW);
                 const float *wb = take((size_t)HW * HW), *bbv = take((size_t)HW);
                 const float *g3 = take((size_t)C * HW), *b3 = take((size_t)C * HW), *c2 = take((size_t)C * C);
-                pack_regfed(fw, c1, C, C);
+                for (int rep = 0; rep < 2; rep++)  // statistics pass, then normalising pass
+                    for (int half = 0; half < 2; half++) pack_regfed(fw, c1 + (size_t)half * (C / 2) * C, C / 2, C);
                 pack_ldsfed(fw, c2, C, C, 1, C, C / 16);
                 pack_gb(T.gb, g1, b1, C, HW);
                 pack_gb(T.gb, g2, b2, C, HW);
                 pack_gb(T.gb, g3, b3, C, HW);
                 // B fragments of the broadcast linear: lane (q = 32qt + r, h) holds Wb[q][16ks + 8h + j]
-                const int KP = n->L.kp, QT = n->L.qt;
+                const int KP = n->Lbc.kp, QT = n->Lbc.qt;
                 T.dev.wboff[i] = (int)(T.wbf.size() / 8);
                 T.dev.bboff[i] = (int)T.bb.size();
                 T.bb.resize(T.bb.size() + (size_t)QT * 32, 0.f);
@@ -1012,7 +1242,6 @@ int mfma_pack_weights(MfmaNet* n, const NetDims& d, const float* blob, size_t co
             fw.pad_to(RING);
         }
     }
-    // heads (shared by both towers): conv rows {policy0, policy1, value} appended to each stream
     const float *pconv = take((size_t)2 * C), *plng = take((size_t)2 * HW), *plnb = take((size_t)2 * HW);
     const float *pfcw = take((size_t)A * 2 * HW), *pfcb = take((size_t)A);
     const float *vconv = take((size_t)C), *vlng = take((size_t)HW), *vlnb = take((size_t)HW);
@@ -1026,7 +1255,7 @@ int mfma_pack_weights(MfmaNet* n, const NetDims& d, const float* blob, size_t co
     std::memcpy(hw3.data() + 2 * C, vconv, (size_t)C * 4);
     for (int t = 0; t < 2; t++) {
         const void* p;
-        if (upload(n, th[t].stream, &p, (size_t)RING * 1024 * 2, err)) return -1;
+        if (upload(n, th[t].stream, &p, (size_t)RING * 1024 * 2, err)) return -1;  // the ring prefetches past the end
         th[t].dev.stream = (const u32x4*)p;
         if (upload(n, th[t].gb, &p, 64, err)) return -1;
         th[t].dev.gb = (const u32x4*)p;
@@ -1063,26 +1292,60 @@ int mfma_pack_weights(MfmaNet* n, const NetDims& d, const float* blob, size_t co
     return 0;
 }
 
+namespace {
+
+template <int IN, int OUT>
+void launch_seg(MfmaNet* n, hipStream_t st, int grid, const NetDims& d, const TowerDev& tw, const NetIO& io, int b0,
+                int b1) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_seg<128, 64, IN, OUT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_seg<128, 64, IN, OUT>), dim3(grid), dim3(NT), n->Lseg.total, st, d, tw, n->hd, io, n->Lseg,
+                       n->NB, b0, b1);
+}
+
+}  // namespace
+
 int mfma_forward(MfmaNet* n, hipStream_t st, bool initial, const NetDims& d, const NetIO& io, std::string* err) {
     if (!n || !n->packed) {
         if (err) *err = "mfma weights not packed";
         return -1;
     }
     const int grid = (io.B + n->NB - 1) / n->NB;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_net_mfma<128, 64, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_net_mfma<128, 64, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+    const TowerDev& tw = n->tw[initial ? 0 : 1];
+    // runs of bottleneck blocks separated by broadcast blocks
+    int b = 0;
+    bool first = true;
+    while (true) {
+        int e = b;
+        while (e < d.R && tw.type[e] == 0) e++;
+        const bool last = e == d.R;
+        if (first) {
+            if (initial) {
+                if (last) launch_seg<IN_OBS, OUT_FINAL>(n, st, grid, d, tw, io, b, e);
+                else launch_seg<IN_OBS, OUT_X>(n, st, grid, d, tw, io, b, e);
+            } else {
+                if (last) launch_seg<IN_HIDDEN, OUT_FINAL>(n, st, grid, d, tw, io, b, e);
+                else launch_seg<IN_HIDDEN, OUT_X>(n, st, grid, d, tw, io, b, e);
+            }
+        } else {
+            if (last) launch_seg<IN_X, OUT_FINAL>(n, st, grid, d, tw, io, b, e);
+            else launch_seg<IN_X, OUT_X>(n, st, grid, d, tw, io, b, e);
+        }
+        first = false;
+        if (last) break;
+        static bool bc_attr = false;
+        if (!bc_attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bcast<128>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            bc_attr = true;
+        }
+        hipLaunchKernelGGL((k_bcast<128>), dim3(grid), dim3(NT), n->Lbc.total, st, d, tw, io, n->Lbc, n->NB, e);
+        b = e + 1;
     }
-    if (initial)
-        hipLaunchKernelGGL((k_net_mfma<128, 64, true>), dim3(grid), dim3(NT), n->L.total, st, d, n->tw[0], n->hd, io,
-                           n->L, n->NB);
-    else
-        hipLaunchKernelGGL((k_net_mfma<128, 64, false>), dim3(grid), dim3(NT), n->L.total, st, d, n->tw[1], n->hd, io,
-                           n->L, n->NB);
     return 0;
 }
 
