@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmuzero_hip.so")
+LIB_PATH = os.environ.get("MZ_LIB", os.path.join(_HERE, "libmuzero_hip.so"))  # MZ_LIB: diagnostic builds
 
 PRECISION_FP32 = 0
 PRECISION_BF16 = 1

@@ -49,6 +49,14 @@ constexpr int ZROW = COLS;     // LDS row of zeros (off-board neighbours, padded
 constexpr int RING = 16;       // A-fragment prefetch depth per wave
 constexpr int MAXNB = 32;      // boards per workgroup upper bound (COLS / 9 = 28)
 
+#if defined(MZ_STAMPS)  // diagnostic build: per-phase cycle counts of workgroup 0 / wave 0, printed by the kernel
+#define STAMP(i) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += (unsigned)(t_ - st_last); st_last = t_; } while (0)
+#define STAMP_DECL unsigned st_acc[12] = {0}; unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#else
+#define STAMP(i)
+#define STAMP_DECL
+#endif
+
 enum { IN_OBS = 0, IN_HIDDEN = 1, IN_X = 2 };
 enum { OUT_X = 0, OUT_FINAL = 1 };
 
@@ -82,7 +90,11 @@ struct LdsPlan {
     int kp, qt;
 };
 
+#if defined(MZ_ABL_NOBARRIER)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#else
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#endif
 
 __device__ __forceinline__ bf16x8 pack8(const float* y) {
     bf16x8 r;
@@ -113,6 +125,9 @@ struct Ring {
         for (int i = 0; i < RING; i++) s[i] = ld(i);
     }
     __device__ __forceinline__ bf16x8 get(int i) {
+#if defined(MZ_ABL_NORING)
+        return __builtin_bit_cast(bf16x8, s[i % RING]);
+#endif
         u32x4 r = s[i % RING];
         s[i % RING] = ld(i + RING);
         // Pin the refill HERE: without this the scheduler sinks each load down to just before its use
@@ -137,49 +152,87 @@ struct Ctx {
     char* smem;
     LdsPlan L;
     int HW, NB, Wd, lane, wave, h, r;
-    float* colsum;   // [COLS][2]
-    float* bstat;    // [MAXNB+1][2] (+ per-wave partials in the broadcast kernel)
+    float* wpart;    // [2][4 waves][MAXNB][2] per-wave board partials (double buffered)
+    int parity;
+    float* bstat;    // [MAXNB+1][2] + [4][MAXNB][2] (broadcast kernel's own per-board statistics)
     int* meta;       // [4][MAXNB]: src slot, dst slot, live, action cell
 };
 
+// Wave-wide reductions on the DPP path (quad_perm / row_ror inside rows of 16 lanes, then v_readlane of the
+// four row totals).  __shfl_xor compiles to ds_bpermute_b32, whose ~100-cycle latency in a dependent
+// chain made every LayerNorm statistic cost thousands of cycles.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float rl(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+template <int MODE>  // 0 add, 1 min, 2 max; result is wave-uniform
+__device__ __forceinline__ float wave_red(float v) {
+#define MZ_OP(a, b) (MODE == 0 ? (a) + (b) : (MODE == 1 ? fminf((a), (b)) : fmaxf((a), (b))))
+    v = MZ_OP(v, dpp_f<0xB1>(v));   // quad_perm [1,0,3,2]
+    v = MZ_OP(v, dpp_f<0x4E>(v));   // quad_perm [2,3,0,1]
+    v = MZ_OP(v, dpp_f<0x124>(v));  // row_ror:4
+    v = MZ_OP(v, dpp_f<0x128>(v));  // row_ror:8
+    const float a = MZ_OP(rl(v, 0), rl(v, 16)), b = MZ_OP(rl(v, 32), rl(v, 48));
+    return MZ_OP(a, b);
+#undef MZ_OP
+}
+
 // Per-board reduction of per-column partials. MODE 0: (sum, sumsq) -> (mean, rstd); MODE 1: (min, max).
+// Two levels, one barrier: (1) inside each wave a masked butterfly per board that the wave's 64 columns
+// touch (at most 2 boards for 9x9, more for small boards), lane b keeping board b's value; (2) lanes < NB
+// publish wpart[parity][wave][board] (zeros / neutral where the wave holds none of the board), barrier,
+// and every lane adds the four wave partials of its own boards.  wpart alternates between two buffers so
+// the next reduction's writes cannot overtake this one's reads.
 template <int MODE>
-__device__ __forceinline__ void board_reduce(const Ctx& c, const Cols& k, float (&a)[TC], float (&b)[TC], float n_inv) {
+__device__ __forceinline__ void board_reduce(Ctx& c, const Cols& k, float (&a)[TC], float (&b)[TC], float n_inv) {
+    const float na = MODE == 0 ? 0.f : INFINITY, nb = MODE == 0 ? 0.f : -INFINITY;
+    // board range of this wave (wave-uniform): columns 64*wave .. 64*wave+63
+    const int bmin = (64 * c.wave) / c.HW;
+    int bmax = (64 * c.wave + 63) / c.HW;
+    if (bmax > c.NB - 1) bmax = c.NB - 1;
+    float ma = na, mb = nb;
+    for (int bd = bmin; bd <= bmax; bd++) {
+        float x = na, y = nb;
 #pragma unroll
-    for (int ct = 0; ct < TC; ct++) {
-        float oa = __shfl_xor(a[ct], 32), ob = __shfl_xor(b[ct], 32);
-        if (MODE == 0) {
-            a[ct] += oa;
-            b[ct] += ob;
-        } else {
-            a[ct] = fminf(a[ct], oa);
-            b[ct] = fmaxf(b[ct], ob);
-        }
-        if (c.h == 0) {
-            c.colsum[2 * k.col[ct]] = a[ct];
-            c.colsum[2 * k.col[ct] + 1] = b[ct];
-        }
-    }
-    lds_barrier();
-    {
-        const int t = threadIdx.x;
-        const int bd = t >> 3, part = t & 7;
-        float x = MODE == 0 ? 0.f : INFINITY, y = MODE == 0 ? 0.f : -INFINITY;
-        if (bd < c.NB) {
-            for (int i = part; i < c.HW; i += 8) {
-                float u = c.colsum[2 * (bd * c.HW + i)], v = c.colsum[2 * (bd * c.HW + i) + 1];
-                if (MODE == 0) {
-                    x += u;
-                    y += v;
-                } else {
-                    x = fminf(x, u);
-                    y = fmaxf(y, v);
-                }
+        for (int ct = 0; ct < TC; ct++) {
+            const bool in = k.board[ct] == bd;
+            if (MODE == 0) {
+                x += in ? a[ct] : 0.f;
+                y += in ? b[ct] : 0.f;
+            } else {
+                x = fminf(x, in ? a[ct] : INFINITY);
+                y = fmaxf(y, in ? b[ct] : -INFINITY);
             }
         }
+        if (MODE == 0) {
+            x = wave_red<0>(x);
+            y = wave_red<0>(y);
+        } else {
+            x = wave_red<1>(x);
+            y = wave_red<2>(y);
+        }
+        if (c.lane == bd) {
+            ma = x;
+            mb = y;
+        }
+    }
+    float* wp = c.wpart + c.parity * (4 * MAXNB * 2);
+    c.parity ^= 1;
+    if (c.lane < c.NB) {
+        wp[(c.wave * MAXNB + c.lane) * 2] = ma;
+        wp[(c.wave * MAXNB + c.lane) * 2 + 1] = mb;
+    }
+    lds_barrier();
 #pragma unroll
-        for (int o = 1; o < 8; o <<= 1) {
-            float u = __shfl_xor(x, o), v = __shfl_xor(y, o);
+    for (int ct = 0; ct < TC; ct++) {
+        const int bd = k.board[ct] < MAXNB ? k.board[ct] : 0;
+        float x = na, y = nb;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const float u = wp[(w * MAXNB + bd) * 2], v = wp[(w * MAXNB + bd) * 2 + 1];
             if (MODE == 0) {
                 x += u;
                 y += v;
@@ -188,54 +241,44 @@ __device__ __forceinline__ void board_reduce(const Ctx& c, const Cols& k, float 
                 y = fmaxf(y, v);
             }
         }
-        if (bd < c.NB && part == 0) {
-            if (MODE == 0) {
-                float mean = x * n_inv;
-                float var = fmaxf(y * n_inv - mean * mean, 0.f);
-                c.bstat[2 * bd] = mean;
-                c.bstat[2 * bd + 1] = 1.0f / sqrtf(var + 1e-5f);
-            } else {
-                c.bstat[2 * bd] = x;
-                c.bstat[2 * bd + 1] = y;
-            }
+        if (MODE == 0) {
+            const float mean = x * n_inv;
+            const float var = fmaxf(y * n_inv - mean * mean, 0.f);
+            a[ct] = k.valid[ct] ? mean : 0.f;
+            b[ct] = k.valid[ct] ? 1.0f / sqrtf(var + 1e-5f) : 0.f;   // padded columns: neutral statistics
+        } else {
+            a[ct] = k.valid[ct] ? x : 0.f;
+            b[ct] = k.valid[ct] ? y : 1.f;
         }
-        if (t == 0) {  // neutral entry for padded columns
-            c.bstat[2 * MAXNB] = 0.f;
-            c.bstat[2 * MAXNB + 1] = MODE == 0 ? 0.f : 1.f;
-        }
-    }
-    lds_barrier();
-#pragma unroll
-    for (int ct = 0; ct < TC; ct++) {
-        a[ct] = c.bstat[2 * k.board[ct]];
-        b[ct] = c.bstat[2 * k.board[ct] + 1];
     }
 }
 
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+
 // LayerNorm statistics of NRT row tiles (all channels) x own columns -> per-column (mean, rstd).
 template <int NRT>
-__device__ __forceinline__ void ln_stats(const Ctx& c, const Cols& k, const f32x16 (&v)[NRT][TC], int nch,
+__device__ __forceinline__ void ln_stats(Ctx& c, const Cols& k, const f32x16 (&v)[NRT][TC], int nch,
                                          float (&mean)[TC], float (&rstd)[TC]) {
 #pragma unroll
     for (int ct = 0; ct < TC; ct++) {
-        float s = 0.f, q = 0.f;
+        f32x2_t s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
 #pragma unroll
         for (int rt = 0; rt < NRT; rt++)
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-                float x = v[rt][ct][i];
-                s += x;
-                q = fmaf(x, x, q);
+            for (int i = 0; i < 16; i += 2) {
+                f32x2_t x = {v[rt][ct][i], v[rt][ct][i + 1]};
+                s2 += x;
+                q2 = x * x + q2;
             }
-        mean[ct] = k.valid[ct] ? s : 0.f;
-        rstd[ct] = k.valid[ct] ? q : 0.f;
+        mean[ct] = k.valid[ct] ? s2.x + s2.y : 0.f;
+        rstd[ct] = k.valid[ct] ? q2.x + q2.y : 0.f;
     }
     board_reduce<0>(c, k, mean, rstd, 1.0f / (float)(nch * c.HW));
 }
 
 // gamma/beta of row tile rt for both column tiles: 4 x 16-byte loads per column
 // (uniform base + 32-bit per-lane offset + immediate).
-__device__ __forceinline__ void gb_load(const u32x4* gb, int cn4, const Ctx& c, const Cols& k, int rt,
+__device__ __forceinline__ void gb_load(const u32x4* gb, int cn4, Ctx& c, const Cols& k, int rt,
                                         u32x4 (&g)[TC][4]) {
 #pragma unroll
     for (int ct = 0; ct < TC; ct++) {
@@ -260,6 +303,46 @@ __device__ __forceinline__ void ln_apply(const f32x16& v, float mean, float rstd
     }
 }
 
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) short s16x2;
+
+// Packed variant for the hot blocks: o[j] = bf16x2 of relu(LN(v)) rows (2j, 2j+1).  Per element: half a
+// v_pk_fma_f32 (normalise), one v_fma_mix_f32 (fp16 gamma/beta), half a v_cvt_pk_bf16_f32 and half a
+// v_pk_max_i16 (ReLU on the packed bf16 pair: a negative bf16 is a negative int16).
+__device__ __forceinline__ void ln_apply_pk(const f32x16& v, float rstd, float nmr, const u32x4 (&g)[4],
+                                            unsigned (&o)[8]) {
+    const f32x2 a2 = {rstd, rstd}, n2 = {nmr, nmr};
+#pragma unroll
+    for (int qd = 0; qd < 4; qd++) {
+        f16x8 hv = __builtin_bit_cast(f16x8, g[qd]);
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) {
+            f32x2 x = {v[4 * qd + e], v[4 * qd + e + 1]};
+            f32x2 t = x * a2 + n2;
+            // two scalar v_fma_mix_f32 (f32 * f16 + f16, no conversions) feeding one v_cvt_pk_bf16_f32; the
+            // asm also keeps the SLP vectoriser from turning the pair into v_pk_fma_f32 + 4 x v_cvt_f32_f16
+            const float y0 = fmaf(t.x, (float)hv[e], (float)hv[4 + e]);
+            const float y1 = fmaf(t.y, (float)hv[e + 1], (float)hv[4 + e + 1]);
+            unsigned pk;
+            asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(y0), "v"(y1));
+            s16x2 r = __builtin_elementwise_max(__builtin_bit_cast(s16x2, pk), (s16x2){0, 0});
+            o[2 * qd + e / 2] = __builtin_bit_cast(unsigned, r);
+        }
+    }
+}
+__device__ __forceinline__ bf16x8 frag_of(const unsigned (&o)[8], int s) {
+    u32x4 r = {o[4 * s], o[4 * s + 1], o[4 * s + 2], o[4 * s + 3]};
+    return __builtin_bit_cast(bf16x8, r);
+}
+__device__ __forceinline__ void act_store_pk(char* act, int rs, int col, int rt, int h, const unsigned (&o)[8]) {
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+#pragma unroll
+    for (int qd = 0; qd < 4; qd++) {
+        u32x2 w = {o[2 * qd], o[2 * qd + 1]};
+        *reinterpret_cast<u32x2*>(act + col * rs + (32 * rt + 8 * qd + 4 * h) * 2) = w;
+    }
+}
+
 // Write the 16 rows of (row tile rt, column tile) as bf16 into the [column][channel] LDS image.
 __device__ __forceinline__ void act_store(char* act, int rs, int col, int rt, int h, const float (&y)[16]) {
 #pragma unroll
@@ -267,12 +350,20 @@ __device__ __forceinline__ void act_store(char* act, int rs, int col, int rt, in
         *reinterpret_cast<bf16x4*>(act + col * rs + (32 * rt + 8 * qd + 4 * h) * 2) = pack4(&y[4 * qd]);
 }
 
+#if defined(MZ_ABL_NOMFMA)   // diagnostic builds only (tools/ablate.sh): keep operands alive, drop the matrix op
+__device__ __forceinline__ f32x16 mfma_stub(bf16x8 a, bf16x8 b, f32x16 c) {
+    asm volatile("" ::"v"(a), "v"(b));
+    return c;
+}
+#define MFMA(a, b, c) mfma_stub((a), (b), (c))
+#else
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+#endif
 
 // out[ro][ct] += W * relu(LN(in)) with the B operand taken from the accumulator registers `in`.
 // Fragment order in the stream: (rt_in, s, ro).
 template <int NRI, int NRO>
-__device__ __forceinline__ void conv1x1_regfed_core(const Ctx& c, const Cols& k, Ring& ring, int& fi, const u32x4* gb,
+__device__ __forceinline__ void conv1x1_regfed_core(Ctx& c, const Cols& k, Ring& ring, int& fi, const u32x4* gb,
                                                     const f32x16 (&in)[NRI][TC], f32x16 (&out)[NRO][TC],
                                                     const float (&mean)[TC], const float (&rstd)[TC]) {
     u32x4 g[TC][4];
@@ -299,21 +390,21 @@ __device__ __forceinline__ void conv1x1_regfed_core(const Ctx& c, const Cols& k,
     }
 }
 template <int NRI, int NRO>
-__device__ __forceinline__ void conv1x1_regfed(const Ctx& c, const Cols& k, Ring& ring, int& fi, const u32x4* gb,
+__device__ __forceinline__ void conv1x1_regfed(Ctx& c, const Cols& k, Ring& ring, int& fi, const u32x4* gb,
                                                const f32x16 (&in)[NRI][TC], f32x16 (&out)[NRO][TC]) {
     float mean[TC], rstd[TC];
     ln_stats<NRI>(c, k, in, NRI * 32, mean, rstd);
     conv1x1_regfed_core<NRI, NRO>(c, k, ring, fi, gb, in, out, mean, rstd);
 }
 
-__device__ __forceinline__ int nb_row(const Ctx& c, const Cols& k, int ct, int t) {
+__device__ __forceinline__ int nb_row(Ctx& c, const Cols& k, int ct, int t) {
     return ((k.nbmask[ct] >> t) & 1u) ? k.col[ct] + (t / 3 - 1) * c.Wd + (t % 3 - 1) : ZROW;
 }
 
 // LN + ReLU of `in` (NRI row tiles) into the LDS image, then out += conv3x3(image).
 // Fragment order: (tap, ks, ro).
 template <int NRI, int NRO>
-__device__ __forceinline__ void conv3x3_ldsfed(const Ctx& c, const Cols& k, Ring& ring, int& fi, const u32x4* gb,
+__device__ __forceinline__ void conv3x3_ldsfed(Ctx& c, const Cols& k, Ring& ring, int& fi, const u32x4* gb,
                                                const f32x16 (&in)[NRI][TC], f32x16 (&out)[NRO][TC]) {
     constexpr int RS = NRI * 64 + 16;
     char* act = c.smem + c.L.act_off;
@@ -375,28 +466,23 @@ template <int C, int CB>
 struct GRing {
     static constexpr int NRC = C / 32, NRB = CB / 32, NCH = NRC + 3 * NRB;
     u32x4 g[2][TC][4];
-    unsigned offC[TC], offB[TC];  // per-lane byte offsets (p * cn4 + h) * 16 for cn4 = C/4 and CB/4
-    __device__ __forceinline__ void init(const Ctx& c, const Cols& k) {
-#pragma unroll
-        for (int ct = 0; ct < TC; ct++) {
-            offC[ct] = (unsigned)(k.p[ct] * (C / 4) + c.h) * 16u;
-            offB[ct] = (unsigned)(k.p[ct] * (CB / 4) + c.h) * 16u;
-        }
+    unsigned lane_off;  // (wave * TC * 4 * 64 + lane) * 16 bytes
+    __device__ __forceinline__ void init(Ctx& c, const Cols&) {
+        lane_off = (unsigned)(c.wave * TC * 4 * 64 + c.lane) * 16u;
     }
-    // chunk j (0 <= j < 2*NCH; j >= NCH addresses the NEXT block) into slot j % 2
-    __device__ __forceinline__ void load(int j, const char* gbb, const char* gbn, int HW) {
+    // chunk j (0 <= j < 2*NCH; j >= NCH addresses the NEXT block) into slot j % 2.
+    // Memory layout of a bottleneck block's gamma/beta (pack_gb_cols): per LayerNorm, per row tile,
+    // [wave][ct][qd][lane] x 16 bytes - every wave-load is one contiguous KiB.
+    __device__ __forceinline__ void load(int j, const char* gbb, const char* gbn) {
         const char* base = j >= NCH ? gbn : gbb;
         const int jj = j >= NCH ? j - NCH : j;
-        const bool wide = jj < NRC;
-        const int ln = wide ? 0 : 1 + (jj - NRC) / NRB;      // which LayerNorm of the block
-        const int rt = wide ? jj : (jj - NRC) % NRB;
-        const size_t sec = wide ? 0 : ((size_t)HW * (C / 4) + (size_t)(ln - 1) * HW * (CB / 4)) * 16;
+        const int chunk_bytes = 4 * TC * 4 * 64 * 16;  // one row tile: 4 waves x TC x 4 qd x 1 KiB
 #pragma unroll
         for (int ct = 0; ct < TC; ct++)
 #pragma unroll
             for (int qd = 0; qd < 4; qd++)
-                g[j % 2][ct][qd] = *reinterpret_cast<const u32x4*>(base + sec + (wide ? offC[ct] : offB[ct]) +
-                                                                   (8 * rt + 2 * qd) * 16);
+                g[j % 2][ct][qd] = *reinterpret_cast<const u32x4*>(base + (size_t)jj * chunk_bytes + lane_off +
+                                                                   (ct * 4 + qd) * 1024);
         __builtin_amdgcn_sched_barrier(0x38F);
     }
 };
@@ -404,8 +490,12 @@ struct GRing {
 // BottleneckResidualBlock: x + c4(relu(LN(c3(relu(LN(c2(relu(LN(c1(relu(LN(x))))))))))))
 // On entry the gamma/beta ring holds chunks 0 and 1 of this block; on exit chunks 0 and 1 of the next.
 template <int C, int CB>
-__device__ __forceinline__ void bottleneck(const Ctx& c, const Cols& k, Ring& ring, GRing<C, CB>& gr, const char* gbb,
-                                           const char* gbn, f32x16 (&X)[C / 32][TC]) {
+__device__ __forceinline__ void bottleneck(Ctx& c, const Cols& k, Ring& ring, GRing<C, CB>& gr, const char* gbb,
+                                           const char* gbn, f32x16 (&X)[C / 32][TC]
+#if defined(MZ_STAMPS)
+                                           , unsigned (&st_acc)[12], unsigned long long& st_last
+#endif
+                                           ) {
     constexpr int NRC = C / 32, NRB = CB / 32;
     constexpr int RS = CB * 2 + 16;
     char* act = c.smem + c.L.act_off;
@@ -414,19 +504,16 @@ __device__ __forceinline__ void bottleneck(const Ctx& c, const Cols& k, Ring& ri
     f32x16 a1[NRB][TC], a2[NRB][TC];
 
     // ---- LN1 + c1 (C -> CB), B operand straight from X ----
+    STAMP(0);
     ln_stats<NRC>(c, k, X, C, mean, rstd);
+    STAMP(1);
     zero_acc<NRB>(a1);
 #pragma unroll
     for (int rt = 0; rt < NRC; rt++) {
-        bf16x8 bf[TC][2];
+        unsigned o[TC][8];
 #pragma unroll
-        for (int ct = 0; ct < TC; ct++) {
-            float y[16];
-            ln_apply(X[rt][ct], mean[ct], rstd[ct], gr.g[gj % 2][ct], y);
-            bf[ct][0] = pack8(&y[0]);
-            bf[ct][1] = pack8(&y[8]);
-        }
-        gr.load(gj + 2, gbb, gbn, c.HW);
+        for (int ct = 0; ct < TC; ct++) ln_apply_pk(X[rt][ct], rstd[ct], -mean[ct] * rstd[ct], gr.g[gj % 2][ct], o[ct]);
+        gr.load(gj + 2, gbb, gbn);
         gj++;
 #pragma unroll
         for (int s = 0; s < 2; s++)
@@ -434,7 +521,7 @@ __device__ __forceinline__ void bottleneck(const Ctx& c, const Cols& k, Ring& ri
             for (int ro = 0; ro < NRB; ro++) {
                 bf16x8 a = ring.get(fi++);
 #pragma unroll
-                for (int ct = 0; ct < TC; ct++) a1[ro][ct] = MFMA(a, bf[ct][s], a1[ro][ct]);
+                for (int ct = 0; ct < TC; ct++) a1[ro][ct] = MFMA(a, frag_of(o[ct], s), a1[ro][ct]);
             }
     }
     // ---- LN2 -> image -> c2 (3x3), LN3 -> image -> c3 (3x3) ----
@@ -442,57 +529,62 @@ __device__ __forceinline__ void bottleneck(const Ctx& c, const Cols& k, Ring& ri
     for (int layer = 0; layer < 2; layer++) {
         f32x16 (&in)[NRB][TC] = layer == 0 ? a1 : a2;
         f32x16 (&out)[NRB][TC] = layer == 0 ? a2 : a1;
+        STAMP(2);
         ln_stats<NRB>(c, k, in, CB, mean, rstd);
+        STAMP(3);
 #pragma unroll
         for (int rt = 0; rt < NRB; rt++) {
 #pragma unroll
             for (int ct = 0; ct < TC; ct++) {
-                float y[16];
-                ln_apply(in[rt][ct], mean[ct], rstd[ct], gr.g[gj % 2][ct], y);
-                if (!k.valid[ct]) {
-#pragma unroll
-                    for (int i = 0; i < 16; i++) y[i] = 0.f;
-                }
-                act_store(act, RS, k.col[ct], rt, c.h, y);
+                // padded columns: gamma = beta = 0 in the packed table and (mean, rstd) = (0, 0) => zeros
+                unsigned o[8];
+                ln_apply_pk(in[rt][ct], rstd[ct], -mean[ct] * rstd[ct], gr.g[gj % 2][ct], o);
+                act_store_pk(act, RS, k.col[ct], rt, c.h, o);
             }
-            gr.load(gj + 2, gbb, gbn, c.HW);
+            gr.load(gj + 2, gbb, gbn);
             gj++;
         }
+        STAMP(4);
         lds_barrier();
+        STAMP(5);
         zero_acc<NRB>(out);
+        // B fragments are read one k-step ahead of the MFMAs that use them (LDS latency hidden behind
+        // the 4 MFMAs of the current k-step); the DS reads are pinned above the MFMAs.
+        constexpr int KS = NRB * 2, NK = 9 * KS;
+        bf16x8 bcur[TC], bnxt[TC];
 #pragma unroll
-        for (int t = 0; t < 9; t++) {
-            int row[TC];
+        for (int ct = 0; ct < TC; ct++)
+            bcur[ct] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(act + nb_row(c, k, ct, 0) * RS + (8 * c.h) * 2));
 #pragma unroll
-            for (int ct = 0; ct < TC; ct++) row[ct] = nb_row(c, k, ct, t);
-#pragma unroll
-            for (int ks = 0; ks < NRB * 2; ks++) {
-                bf16x8 b[TC];
+        for (int kk = 0; kk < NK; kk++) {
+            if (kk + 1 < NK) {
+                const int t = (kk + 1) / KS, ks = (kk + 1) % KS;
 #pragma unroll
                 for (int ct = 0; ct < TC; ct++)
-                    b[ct] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(act + row[ct] * RS + (16 * ks + 8 * c.h) * 2));
-#pragma unroll
-                for (int ro = 0; ro < NRB; ro++) {
-                    bf16x8 a = ring.get(fi++);
-#pragma unroll
-                    for (int ct = 0; ct < TC; ct++) out[ro][ct] = MFMA(a, b[ct], out[ro][ct]);
-                }
+                    bnxt[ct] = __builtin_bit_cast(
+                        bf16x8, *reinterpret_cast<const u32x4*>(act + nb_row(c, k, ct, t) * RS + (16 * ks + 8 * c.h) * 2));
+                __builtin_amdgcn_sched_barrier(0x7F);  // everything but DS instructions may cross
             }
+#pragma unroll
+            for (int ro = 0; ro < NRB; ro++) {
+                bf16x8 a = ring.get(fi++);
+#pragma unroll
+                for (int ct = 0; ct < TC; ct++) out[ro][ct] = MFMA(a, bcur[ct], out[ro][ct]);
+            }
+#pragma unroll
+            for (int ct = 0; ct < TC; ct++) bcur[ct] = bnxt[ct];
         }
     }
     // ---- LN4 + c4 (CB -> C) accumulated into X ----
+    STAMP(6);
     ln_stats<NRB>(c, k, a1, CB, mean, rstd);
+    STAMP(7);
 #pragma unroll
     for (int rt = 0; rt < NRB; rt++) {
-        bf16x8 bf[TC][2];
+        unsigned o[TC][8];
 #pragma unroll
-        for (int ct = 0; ct < TC; ct++) {
-            float y[16];
-            ln_apply(a1[rt][ct], mean[ct], rstd[ct], gr.g[gj % 2][ct], y);
-            bf[ct][0] = pack8(&y[0]);
-            bf[ct][1] = pack8(&y[8]);
-        }
-        gr.load(gj + 2, gbb, gbn, c.HW);
+        for (int ct = 0; ct < TC; ct++) ln_apply_pk(a1[rt][ct], rstd[ct], -mean[ct] * rstd[ct], gr.g[gj % 2][ct], o[ct]);
+        gr.load(gj + 2, gbb, gbn);
         gj++;
 #pragma unroll
         for (int s = 0; s < 2; s++)
@@ -500,9 +592,10 @@ __device__ __forceinline__ void bottleneck(const Ctx& c, const Cols& k, Ring& ri
             for (int ro = 0; ro < NRC; ro++) {
                 bf16x8 a = ring.get(fi++);
 #pragma unroll
-                for (int ct = 0; ct < TC; ct++) X[ro][ct] = MFMA(a, bf[ct][s], X[ro][ct]);
+                for (int ct = 0; ct < TC; ct++) X[ro][ct] = MFMA(a, frag_of(o[ct], s), X[ro][ct]);
             }
     }
+    STAMP(8);
     ring.advance(fi);  // 4*NRC*NRB + 36*NRB*NRB fragments: a multiple of RING for the supported shapes
 }
 
@@ -553,30 +646,35 @@ __device__ __forceinline__ void ctx_init(Ctx& c, char* smem, const LdsPlan& L, c
     c.wave = tid >> 6;
     c.h = c.lane >> 5;
     c.r = c.lane & 31;
-    c.colsum = reinterpret_cast<float*>(smem + L.colsum_off);
+    c.wpart = reinterpret_cast<float*>(smem + L.colsum_off);
+    c.parity = 0;
     c.bstat = reinterpret_cast<float*>(smem + L.bstat_off);
     c.meta = reinterpret_cast<int*>(smem + L.meta_off);
 }
 
 // X <-> [slot][C][HW] fp32 in the hidden-state pool (slot index from meta row `which`).
 template <int NRC>
-__device__ __forceinline__ void x_load(const Ctx& c, const Cols& k, const float* pool, int which, int C,
+__device__ __forceinline__ void x_load(Ctx& c, const Cols& k, const float* pool, int which, int C,
                                        f32x16 (&X)[NRC][TC]) {
 #pragma unroll
     for (int ct = 0; ct < TC; ct++) {
+        // unconditional loads (dead columns read slot meta[..][0], which is always a valid slot) + select:
+        // a per-load branch would serialise 256 dependent round trips
         const int bd = k.valid[ct] ? k.board[ct] : 0;
         const float* src = pool + (long long)c.meta[which * MAXNB + bd] * C * c.HW + k.p[ct];
+        const bool keep = k.live[ct];
 #pragma unroll
         for (int rt = 0; rt < NRC; rt++)
 #pragma unroll
             for (int i = 0; i < 16; i++) {
                 const int ch = 32 * rt + (i & 3) + 8 * (i >> 2) + 4 * c.h;
-                X[rt][ct][i] = k.live[ct] ? src[(long long)ch * c.HW] : 0.f;
+                const float v = src[ch * c.HW];
+                X[rt][ct][i] = keep ? v : 0.f;  // select, not multiply: dead slots may hold NaN bit patterns
             }
     }
 }
 template <int NRC>
-__device__ __forceinline__ void x_store(const Ctx& c, const Cols& k, float* pool, int C, const f32x16 (&X)[NRC][TC]) {
+__device__ __forceinline__ void x_store(Ctx& c, const Cols& k, float* pool, int C, const f32x16 (&X)[NRC][TC]) {
 #pragma unroll
     for (int ct = 0; ct < TC; ct++) {
         if (!k.live[ct]) continue;
@@ -596,10 +694,9 @@ __global__ __launch_bounds__(NT, 1) void k_seg(NetDims d, TowerDev tw, HeadDev h
     constexpr int NRC = C / 32;
     constexpr int CIN0 = IN == IN_OBS ? 32 : C + 16;  // input channels of conv0, padded to 16
     constexpr int KS0 = CIN0 / 16;
-    constexpr int KS0P = (KS0 * NRC + RING - 1) / RING * RING / NRC;  // k-steps per tap in the stream (padded)
+    constexpr int F0 = (9 * KS0 * NRC + RING - 1) / RING * RING;  // conv0 fragments in the stream (padded)
     constexpr int RS0 = CIN0 * 2 + 16;
     constexpr int RSB = CB * 2 + 16;
-    static_assert((KS0P * NRC) % RING == 0, "conv0 fragment count per tap must be a multiple of RING");
     const int tid = threadIdx.x;
     Ctx c;
     ctx_init(c, smem, L, d, NB);
@@ -611,6 +708,7 @@ __global__ __launch_bounds__(NT, 1) void k_seg(NetDims d, TowerDev tw, HeadDev h
 
     Ring ring;
     f32x16 X[NRC][TC];
+    STAMP_DECL
     if (IN == IN_X) {
         ring.init(tw.stream + (long long)tw.foff[b0] * 64, c.lane);
         x_load<NRC>(c, k, io.pool, 1, C, X);
@@ -655,26 +753,37 @@ __global__ __launch_bounds__(NT, 1) void k_seg(NetDims d, TowerDev tw, HeadDev h
             }
         }
         lds_barrier();
-        for (int t = 0; t < 9; t++) {
-            int row[TC];
+        {
+            // conv0, fully unrolled: B fragments read one k-step ahead, fragment order (tap, ks, ro),
+            // padded once at the end to a multiple of RING
+            constexpr int NK = 9 * KS0;
+            bf16x8 bcur[TC], bnxt[TC];
 #pragma unroll
-            for (int ct = 0; ct < TC; ct++) row[ct] = nb_row(c, k, ct, t);
+            for (int ct = 0; ct < TC; ct++)
+                bcur[ct] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(act + nb_row(c, k, ct, 0) * RS0 + (8 * c.h) * 2));
+            int fi = 0;
 #pragma unroll
-            for (int ks = 0; ks < KS0; ks++) {
-                bf16x8 b[TC];
+            for (int kk = 0; kk < NK; kk++) {
+                if (kk + 1 < NK) {
+                    const int t = (kk + 1) / KS0, ks = (kk + 1) % KS0;
 #pragma unroll
-                for (int ct = 0; ct < TC; ct++)
-                    b[ct] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(act + row[ct] * RS0 + (16 * ks + 8 * c.h) * 2));
+                    for (int ct = 0; ct < TC; ct++)
+                        bnxt[ct] = __builtin_bit_cast(
+                            bf16x8, *reinterpret_cast<const u32x4*>(act + nb_row(c, k, ct, t) * RS0 + (16 * ks + 8 * c.h) * 2));
+                    __builtin_amdgcn_sched_barrier(0x7F);
+                }
 #pragma unroll
                 for (int ro = 0; ro < NRC; ro++) {
-                    bf16x8 a = ring.get(ks * NRC + ro);
+                    bf16x8 a = ring.get(fi++);
 #pragma unroll
-                    for (int ct = 0; ct < TC; ct++) X[ro][ct] = MFMA(a, b[ct], X[ro][ct]);
+                    for (int ct = 0; ct < TC; ct++) X[ro][ct] = MFMA(a, bcur[ct], X[ro][ct]);
                 }
+#pragma unroll
+                for (int ct = 0; ct < TC; ct++) bcur[ct] = bnxt[ct];
             }
 #pragma unroll
-            for (int i = KS0 * NRC; i < KS0P * NRC; i++) (void)ring.get(i);  // padding fragments of the stream
-            ring.advance(KS0P * NRC);
+            for (int i = NK * NRC; i < F0; i++) (void)ring.get(i);  // padding fragments of the stream
+            ring.advance(F0);
         }
         lds_barrier();
     }
@@ -686,14 +795,23 @@ __global__ __launch_bounds__(NT, 1) void k_seg(NetDims d, TowerDev tw, HeadDev h
         GRing<C, CB> gr;
         gr.init(c, k);
         const char* gbase = reinterpret_cast<const char*>(tw.gb);
-        gr.load(0, gbase + tw.gboff[b0] * 16, nullptr, HW);
-        gr.load(1, gbase + tw.gboff[b0] * 16, nullptr, HW);
+        gr.load(0, gbase + tw.gboff[b0] * 16, nullptr);
+        gr.load(1, gbase + tw.gboff[b0] * 16, nullptr);
         for (int blk = b0; blk < b1; blk++) {
             // the chunks requested past the end of the last block are never used: point them at valid memory
             const int nxt = (blk + 1 < b1) ? blk + 1 : blk;
+#if defined(MZ_STAMPS)
+            bottleneck<C, CB>(c, k, ring, gr, gbase + tw.gboff[blk] * 16, gbase + tw.gboff[nxt] * 16, X, st_acc, st_last);
+#else
             bottleneck<C, CB>(c, k, ring, gr, gbase + tw.gboff[blk] * 16, gbase + tw.gboff[nxt] * 16, X);
+#endif
         }
     }
+#if defined(MZ_STAMPS)
+    if (blockIdx.x == 0 && tid == 0)
+        printf("k_seg<%d,%d> blocks %d..%d stamps(cycles, summed over blocks): pre=%u ln1stats=%u c1=%u lnstats23=%u apply23=%u bar=%u conv33=%u ln4stats=%u c4=%u\n",
+               IN, OUT, b0, b1, st_acc[0], st_acc[1], st_acc[2], st_acc[3], st_acc[4], st_acc[5], st_acc[6], st_acc[7], st_acc[8]);
+#endif
 
     if (OUT == OUT_X) {
         x_store<NRC>(c, k, io.pool, C, X);
@@ -1068,6 +1186,23 @@ void pack_gb(std::vector<unsigned short>& out, const float* g, const float* b, i
         }
 }
 
+// gamma/beta [Cn][HW] for the bottleneck kernels: per row tile, [wave][ct][qd][lane]{g0..3, b0..3} fp16, where
+// lane (r, h) of (wave, ct) owns column 64*wave + 32*ct + r = (board, cell p) and channels 32rt + 8qd + 4h + e.
+void pack_gb_cols(std::vector<unsigned short>& out, const float* g, const float* b, int Cn, int HW, int NB) {
+    for (int rt = 0; rt < Cn / 32; rt++)
+        for (int w = 0; w < 4; w++)
+            for (int ct = 0; ct < TC; ct++)
+                for (int qd = 0; qd < 4; qd++)
+                    for (int l = 0; l < 64; l++) {
+                        const int col = 64 * w + 32 * ct + (l & 31), h = l >> 5;
+                        const bool valid = col < NB * HW;
+                        const int p = valid ? col % HW : 0;
+                        const int ch = 32 * rt + 8 * qd + 4 * h;
+                        for (int e = 0; e < 4; e++) out.push_back(valid ? f2h(g[(size_t)(ch + e) * HW + p]) : 0);
+                        for (int e = 0; e < 4; e++) out.push_back(valid ? f2h(b[(size_t)(ch + e) * HW + p]) : 0);
+                    }
+}
+
 struct TowerHost {
     std::vector<unsigned short> stream, gb, wbf;
     std::vector<float> bb;
@@ -1179,7 +1314,6 @@ int mfma_pack_weights(MfmaNet* n, const NetDims& d, const float* blob, size_t co
     n->nbufs = 0;
     n->packed = false;
     const int C = d.C, Cb = d.Cb, HW = d.HW, A = d.A;
-    const int NRC = C / 32;
     size_t off = 0;
     auto take = [&](size_t cnt) {
         const float* p = blob + off;
@@ -1193,9 +1327,8 @@ int mfma_pack_weights(MfmaNet* n, const NetDims& d, const float* blob, size_t co
         TowerHost& T = th[t];
         FragWriter fw{T.stream};
         const float* w0 = take((size_t)C * cin0[t] * 9);
-        const int ks0 = cin0_pad[t] / 16;
-        const int ks0p = (ks0 * NRC + RING - 1) / RING * RING / NRC;
-        pack_ldsfed(fw, w0, C, cin0[t], 9, cin0_pad[t], ks0p);
+        pack_ldsfed(fw, w0, C, cin0[t], 9, cin0_pad[t], cin0_pad[t] / 16);
+        fw.pad_to(RING);
         for (int i = 0; i < d.R; i++) {
             const bool bc = d.bcast_every_n > 0 && (i % d.bcast_every_n == d.bcast_every_n - 1);
             T.dev.type[i] = bc ? 1 : 0;
@@ -1210,10 +1343,10 @@ int mfma_pack_weights(MfmaNet* n, const NetDims& d, const float* blob, size_t co
                 pack_ldsfed(fw, c2, Cb, Cb, 9, Cb, Cb / 16);
                 pack_ldsfed(fw, c3, Cb, Cb, 9, Cb, Cb / 16);
                 pack_regfed(fw, c4, C, Cb);
-                pack_gb(T.gb, g1, b1, C, HW);
-                pack_gb(T.gb, g2, b2, Cb, HW);
-                pack_gb(T.gb, g3, b3, Cb, HW);
-                pack_gb(T.gb, g4, b4, Cb, HW);
+                pack_gb_cols(T.gb, g1, b1, C, HW, n->NB);
+                pack_gb_cols(T.gb, g2, b2, Cb, HW, n->NB);
+                pack_gb_cols(T.gb, g3, b3, Cb, HW, n->NB);
+                pack_gb_cols(T.gb, g4, b4, Cb, HW, n->NB);
             } else {
                 const float *g1 = take((size_t)C * HW), *b1 = take((size_t)C * HW), *c1 = take((size_t)C * C);
                 const float *g2 = take((size_t)C * HW), *b2 = take((size_t)C * HW);
