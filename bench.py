@@ -93,24 +93,21 @@ def main():
     ap.add_argument("--workload", default="go9", choices=sorted(WORKLOADS))
     ap.add_argument("--games", type=int, default=4096, help="concurrent games per GPU")
     ap.add_argument("--precision", default="bf16", choices=["fp32", "bf16"])
-    ap.add_argument("--cpu-games", type=int, default=2048, help="games in the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-games", type=int, default=1024, help="games in the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     from muzero_amd import capi, netspec
+    from muzero_amd import dist as mzd
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world, rank, local_rank = mzd.world()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+    mzd.init("nccl", dev)
 
     spec_name, n, m, c_visit, bounds = WORKLOADS[args.workload]
     spec = netspec.SPECS[spec_name]()
@@ -123,10 +120,8 @@ def main():
     # weights: rank 0 draws them, RCCL broadcasts the blob over xGMI, every rank repacks locally
     weights = netspec.random_weights(spec, seed=1) if rank == 0 or world == 1 else None
     if world > 1:
-        wt = torch.empty(netspec.num_params(spec), dtype=torch.float32, device=dev)
-        if rank == 0:
-            wt.copy_(torch.from_numpy(netspec.pack_blob(spec, weights)))
-        dist.broadcast(wt, src=0)
+        wt = mzd.blob_tensor(spec, weights, dev)
+        mzd.broadcast_weights(wt, src=0)
         torch.cuda.synchronize()
         ctx.load_weights(wt)
     else:
@@ -151,8 +146,7 @@ def main():
     def sync():
         ctx.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        mzd.barrier()
 
     def step(g):
         ctx.search_moves(B, obs, legal, gumbel=g, outputs=outs)
@@ -180,16 +174,8 @@ def main():
     assert int(outs["status"].abs().sum().item()) == 0
 
     # whole-job aggregate: MAX time over ranks, SUM of simulations (episode statistics gathered over RCCL)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        stats = torch.tensor([float(sims_total)], dtype=torch.float64, device=dev)
-        gathered = [torch.zeros_like(stats) for _ in range(world)]
-        dist.all_gather(gathered, stats)
-        dt = float(t.item())
-        sims_all = int(sum(float(x.item()) for x in gathered))
-    else:
-        sims_all = sims_total
+    dt = mzd.max_over_ranks(dt, dev)
+    sims_all = int(mzd.gather_stats([sims_total], dev)[:, 0].sum())
 
     if rank == 0:
         fl = netspec.flops_per_sample(spec)

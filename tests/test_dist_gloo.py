@@ -1,0 +1,71 @@
+"""world_size-2 gloo test of the N>1 host path (runs on CPU): contiguous game sharding, weight-blob
+broadcast from rank 0, gather of per-rank episode statistics, max-over-ranks timing."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+from muzero_amd import dist as mzd
+from muzero_amd import netspec
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, total_games, q):
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    assert mzd.init("gloo")
+    spec = netspec.spec_tiny()
+    weights = netspec.random_weights(spec, seed=7) if rank == 0 else None
+    blob = mzd.blob_tensor(spec, weights, torch.device("cpu"))
+    if rank != 0:
+        blob.fill_(-1.0)
+    mzd.broadcast_weights(blob, src=0)
+    lo, hi = mzd.shard_range(total_games, rank, world)
+    sims = (hi - lo) * 20                                 # every game of the shard runs n = 20 simulations
+    stats = mzd.gather_stats([hi - lo, sims, float(blob.double().sum())])
+    tmax = mzd.max_over_ranks(1.0 + rank)
+    mzd.barrier()
+    q.put((rank, lo, hi, stats.tolist(), tmax, float(blob[:5].sum())))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_sharding_broadcast_and_gather():
+    world, total = 2, 101
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, lo0, hi0, st0, t0, b0), (r1, lo1, hi1, st1, t1, b1) = res
+    assert (lo0, hi0, lo1, hi1) == (0, 51, 51, 101)       # contiguous, complete, no overlap
+    assert st0 == st1                                     # every rank sees the same gathered table
+    st = np.array(st0)
+    assert st[:, 0].sum() == total and st[:, 1].sum() == total * 20
+    assert st[0, 2] == st[1, 2] and b0 == b1              # identical weights after the broadcast
+    ref = netspec.pack_blob(netspec.spec_tiny(), netspec.random_weights(netspec.spec_tiny(), seed=7))
+    assert abs(st[0, 2] - ref.astype(np.float64).sum()) < 1e-3
+    assert t0 == t1 == 2.0                                # MAX over ranks
+
+
+def test_shard_range_partitions_exactly():
+    for total in (0, 1, 7, 4096, 4099):
+        for w in (1, 2, 4, 8):
+            parts = [mzd.shard_range(total, r, w) for r in range(w)]
+            assert parts[0][0] == 0 and parts[-1][1] == total
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in parts]
+            assert max(sizes) - min(sizes) <= 1
