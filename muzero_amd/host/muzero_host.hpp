@@ -1,0 +1,401 @@
+// muzero_host.hpp - host side above the C ABI (include/muzero_hip.h), written in C++ because the
+// reference's host language (Java 21) has no toolchain in this image.  It mirrors the reference's
+// plugin / operator interface for the self-play path, same names and argument meaning, so a reader
+// of the reference finds: Action, OneOfTwoPlayer, Observation, ObservationModelInput, GameDTO,
+// Environment, Game (+ TicTacToe / PegSolitair / Go plugins), NetworkIO, ModelService, PlanAction,
+// PlayParameters, PlayService.  Paths below are relative to
+//   P/ = platform/src/main/java/ai/enpasos/muzero/platform/      G/ = games/<game>/src/main/java/ai/enpasos/muzero/<game>/
+//
+// What differs by design (MI355X-first): the reference runs one thread per game and meets the other
+// games in a polling queue (P/agent/d_model/service/ModelQueue.java:35-59); here all live games step
+// in lock-step and one mz_search_moves call plans one move for all of them on the GPU.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/muzero_hip.h"
+
+namespace muzero {
+
+// P/common/MuZeroException.java
+struct MuZeroException : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+// P/config/PlayerMode.java, P/environment/OneOfTwoPlayer.java:25-58
+enum class PlayerMode { SINGLE_PLAYER, TWO_PLAYERS };
+enum class OneOfTwoPlayer { PLAYER_A = 0, PLAYER_B = 1 };
+inline int getValue(OneOfTwoPlayer p) { return p == OneOfTwoPlayer::PLAYER_A ? -1 : 1; }
+inline float getActionValue(OneOfTwoPlayer p) { return p == OneOfTwoPlayer::PLAYER_A ? 0.f : 1.f; }
+inline OneOfTwoPlayer otherPlayer(OneOfTwoPlayer p) {
+    return p == OneOfTwoPlayer::PLAYER_A ? OneOfTwoPlayer::PLAYER_B : OneOfTwoPlayer::PLAYER_A;
+}
+
+// P/agent/a_loopcontrol/Action.java:27-41 (index is the identity; encode() is the action-cell table
+// handed to mz_set_action_cells, see MuZeroConfig::actionCells)
+struct Action {
+    int index = 0;
+    int getIndex() const { return index; }
+};
+
+// P/agent/e_experience/ObservationTwoPlayers.java:13-36 and ObservationOnePlayer (same with one part)
+struct Observation {
+    int partSize = 0;
+    bool twoPlayers = true;
+    std::vector<uint8_t> partA, partB;
+    // player == nullptr for single-player games; returns the advanced index
+    int addTo(const OneOfTwoPlayer* player, float* rawResult, int index) const;
+};
+
+// P/agent/d_model/ObservationModelInput.java:29-36
+struct ObservationModelInput {
+    std::vector<float> value;
+    std::array<long, 3> shape{};
+};
+
+// P/agent/e_experience/GameDTO.java:42-100 (fields the self-play path appends to)
+struct GameDTO {
+    std::vector<int> actions;
+    std::vector<float> rewards;
+    std::vector<float> entropies;
+    std::vector<std::vector<float>> policyTargets;
+    std::vector<Observation> observations;
+    std::vector<std::vector<float>> playoutPolicy;
+    std::vector<std::vector<uint8_t>> legalActions;
+    std::vector<float> rootValueTargets;
+    std::vector<float> vMix;
+    std::vector<float> rootEntropyValueTargets;
+    std::vector<float> rootEntropyValuesFromInitialInference;
+    std::vector<float> rootValuesFromInitialInference;
+    std::vector<float> legalActionMaxEntropies;
+    bool hybrid = false;
+    long tHybrid = -1;
+    int tdSteps = 0;
+};
+
+enum class PlayTypeKey { PLAYOUT, HYBRID, REANALYSE };
+
+class Game;
+
+// P/config/MuZeroConfig.java: the fields this path reads.  Values of the factory
+// functions come from G/../resources/application.yml of each game.
+struct MuZeroConfig {
+    std::string game;  // "tictactoe" | "go5" | "go9" | "pegsolitair"
+    PlayerMode playerMode = PlayerMode::TWO_PLAYERS;
+    int boardHeight = 3, boardWidth = 3, actionSpaceSize = 9;
+    int numObservationLayers = 3, numActionLayers = 1;
+    int numChannels = 256, numBottleneckChannels = 128, numResiduals = 6, broadcastEveryN = 8;
+    int maxMoves = 9;
+    float komi = 0.f;
+    double discount = 1.0;
+    double valueSpan = 2.0;  // value head scale = valueSpan / 2
+    bool knownBounds = true;
+    double boundMin = -1, boundMax = 1;
+    int initialGumbelM = 4, cVisit = 20;
+    double cScale = 1.0;
+    // playTypes.<key>.*
+    PlayTypeKey playTypeKey = PlayTypeKey::PLAYOUT;
+    int numSimulations = 20, numSimulationsHybrid = 20;
+    double rootDirichletAlpha = 1.2, rootExplorationFraction = 0.0, temperatureRoot = 0.0;
+    bool gumbelActionSelection = true, withGumbel = false;
+    double fractionOfPureExplorationAdded = 0.3, fractionOfPureExploitationAdded = 0.0;
+    int numParallelGamesPlayed = 1000;
+    int tdSteps = 0;
+
+    static MuZeroConfig tictactoe();
+    static MuZeroConfig go(int size);
+    static MuZeroConfig pegsolitair();
+    static MuZeroConfig byName(const std::string& name);
+    void setPlayTypeKey(PlayTypeKey key);  // switches the playTypes.* block like MuZeroConfig.java:404-406
+
+    // MuZeroConfig.java:70-84
+    std::unique_ptr<Game> newGame(bool connectToEnvironment, bool withFirstObservation) const;
+    Action newAction(int index) const;
+    // MuZeroConfig.java:355-362
+    int getNumSimulations(const Game& game) const;
+    // index of the single 1 in Action.encode's [a,H,W] planes, -1 for an all-zero plane (Go pass):
+    // G/config/TicTacToeAction.java:57-61, GoAction.java:67-73, PegSolitairAction.java:57-61
+    std::vector<int32_t> actionCells() const;
+    mz_config toNative(int maxGames, int precision) const;
+};
+
+// P/environment/Environment.java:30-46
+class Environment {
+public:
+    virtual ~Environment() = default;
+    virtual float step(const Action& action) = 0;
+    virtual std::vector<Action> getLegalActions() const = 0;
+    virtual Observation getObservation() const = 0;
+    virtual bool isTerminal() const = 0;
+    virtual std::string render() const = 0;
+};
+
+// P/agent/e_experience/Game.java (abstract methods :162-176, :416-474; concrete :113-117, :165-197, :422-437, :501-507)
+class Game {
+public:
+    explicit Game(const MuZeroConfig& config) : config(config), actionSpaceSize(config.actionSpaceSize) {}
+    virtual ~Game() = default;
+
+    virtual bool terminal() const = 0;
+    virtual const OneOfTwoPlayer* toPlay() const = 0;  // nullptr for single-player games (PegSolitairGame.java:103-105)
+    virtual ObservationModelInput getObservationModelInput(int inputTime) const = 0;
+    virtual void connectToEnvironment() = 0;
+    virtual void replayToPositionInEnvironment(int stateIndex);
+    virtual std::string render() const;
+
+    bool isDone(bool replay) const;
+    std::vector<Action> legalActions() const;
+    std::vector<Action> allActionsInActionSpace() const;
+    void apply(const Action& action);
+    void apply(std::initializer_list<int> actionIndices);
+    void pseudoApplyFromOriginalGame(const Action& action);
+    const float* getReward() const;  // nullptr when no reward yet (Game.java:157-160)
+    ObservationModelInput getObservationModelInput() const;
+    void addObservationFromEnvironment();
+    void addLegalActionFromEnvironment();
+    bool isItExplorationTime() const { return isItExplorationTime(static_cast<int>(gameDTO.actions.size())); }
+    bool isItExplorationTime(int t) const { return t < gameDTO.tHybrid; }
+
+    GameDTO& getGameDTO() { return gameDTO; }
+    const GameDTO& getGameDTO() const { return gameDTO; }
+    Environment* getEnvironment() { return environment.get(); }
+    const MuZeroConfig& getConfig() const { return config; }
+
+    GameDTO gameDTO;
+    std::unique_ptr<GameDTO> originalGameDTO;  // replay / reanalyse (Game.java:67,456-472)
+    bool actionApplied = false;
+
+protected:
+    MuZeroConfig config;
+    int actionSpaceSize;
+    std::unique_ptr<Environment> environment;
+    mutable OneOfTwoPlayer toPlayStorage = OneOfTwoPlayer::PLAYER_A;
+};
+
+// ---- plugins ---------------------------------------------------------------------------------
+// G(tictactoe)/config/TicTacToeEnvironment.java:33-157
+class TicTacToeEnvironment : public Environment {
+public:
+    explicit TicTacToeEnvironment(const MuZeroConfig& c);
+    float step(const Action& action) override;
+    std::vector<Action> getLegalActions() const override;
+    Observation getObservation() const override;
+    bool isTerminal() const override;
+    std::string render() const override;
+    bool hasPlayerWon(OneOfTwoPlayer player) const;
+    OneOfTwoPlayer getPlayerToMove() const { return playerToMove; }
+
+private:
+    int H, W;
+    std::vector<int> board;  // row-major, 0 empty, -1 A, +1 B
+    OneOfTwoPlayer playerToMove = OneOfTwoPlayer::PLAYER_A;
+};
+// G(tictactoe)/config/TicTacToeGame.java:45-118
+class TicTacToeGame : public Game {
+public:
+    using Game::Game;
+    using Game::getObservationModelInput;
+    bool terminal() const override;
+    const OneOfTwoPlayer* toPlay() const override;
+    ObservationModelInput getObservationModelInput(int inputTime) const override;
+    void connectToEnvironment() override;
+};
+
+// G(pegsolitair)/config/environment/Board.java, Point.java, Direction.java, Jump.java, NeighborMap.java
+struct PegBoard {
+    uint8_t peg[8][8]{};  // 1-based [row][col]; value 1 = peg, 0 = hole (only where inRange)
+    PegBoard();
+    static bool outOfBounds(int row, int col);
+    static bool inRange(int row, int col) { return !outOfBounds(row, col); }
+    struct Jump { int row, col, direction; };  // fromPoint + Direction ordinal (N,E,S,W)
+    std::vector<Jump> getLegalJumps() const;
+    void applyJump(const Jump& j);
+    float getScore() const;
+    bool isOnePegInTheMiddle() const { return peg[4][4] != 0; }
+    int numPegs() const;
+    std::string render() const;
+};
+// G(pegsolitair)/config/PegSolitairEnvironment.java:36-83, PegSolitairAdapter.java:14-76
+class PegSolitairEnvironment : public Environment {
+public:
+    explicit PegSolitairEnvironment(const MuZeroConfig&) {}
+    float step(const Action& action) override;
+    std::vector<Action> getLegalActions() const override;
+    Observation getObservation() const override;
+    bool isTerminal() const override;
+    std::string render() const override { return board.render(); }
+    PegBoard board;
+};
+// G(pegsolitair)/config/PegSolitairGame.java:42-111
+class PegSolitairGame : public Game {
+public:
+    using Game::Game;
+    using Game::getObservationModelInput;
+    bool terminal() const override;
+    const OneOfTwoPlayer* toPlay() const override { return nullptr; }
+    ObservationModelInput getObservationModelInput(int inputTime) const override;
+    void connectToEnvironment() override;
+};
+
+// G(go)/config/environment/GoBoard.java, GameState.java, scoring/TerritoryCalculator.java, GameResult.java.
+// Compact restatement: the board is a grid of colours, strings and liberties are recomputed by flood
+// fill; the ko history stores (player, position) pairs exactly instead of Zobrist hashes.
+struct GoBoard {
+    int size = 0;
+    std::vector<int8_t> grid;  // 0 empty, 1 black, 2 white; index (row-1)*size + (col-1)
+    int blackCaptures = 0, whiteCaptures = 0;
+    explicit GoBoard(int size = 0) : size(size), grid(static_cast<size_t>(size) * size, 0) {}
+    int at(int row, int col) const { return grid[(row - 1) * size + col - 1]; }
+    bool inBounds(int row, int col) const { return 1 <= row && row <= size && 1 <= col && col <= size; }
+    GoBoard placeStone(int player, int row, int col) const;           // GoBoard.java:101-138,164-212
+    bool isSelfCapture(int player, int row, int col) const;           // :141-162
+    bool willCapture(int player, int row, int col) const;             // :267-274
+    bool doesMoveFillEye(int player, int row, int col) const;         // :219-262
+    int numLiberties(int row, int col, std::vector<int>* stones = nullptr) const;
+};
+struct GoGameResult {  // scoring/GameResult.java:28-113
+    int numBlackStones = 0, numWhiteStones = 0, numBlackTerritory = 0, numWhiteTerritory = 0;
+    int numBlackCaptures = 0, numWhiteCaptures = 0, numDame = 0;
+    float komi = 0;
+    static GoGameResult apply(const GoBoard& board, float komi);
+    int blackPoints() const { return numBlackTerritory + numBlackStones; }
+    int whitePoints() const { return numWhiteTerritory + numWhiteStones; }
+    float blackWinningMargin() const { return blackPoints() - (whitePoints() + komi); }
+};
+// G(go)/config/GoEnvironment.java:45-127 over GameState.java:30-149
+class GoEnvironment : public Environment {
+public:
+    explicit GoEnvironment(const MuZeroConfig& c);
+    float step(const Action& action) override;
+    std::vector<Action> getLegalActions() const override;
+    Observation getObservation() const override;
+    bool isTerminal() const override;
+    std::string render() const override;
+    bool isValidMove(int row, int col) const;  // GameState.java:108-116
+    const GoBoard& getBoard() const { return board; }
+    int getNextPlayer() const { return nextPlayer; }
+    const GoGameResult* getResult() const { return hasResult ? &result : nullptr; }
+
+private:
+    int size, A;
+    float komi;
+    GoBoard board;
+    int nextPlayer = 1;                 // 1 black, 2 white
+    int lastMove = 0, secondLastMove = 0;  // 0 none, 1 play, 2 pass
+    std::vector<std::pair<int, std::vector<int8_t>>> allPreviousStates;
+    GoGameResult result;
+    bool hasResult = false;
+};
+// G(go)/config/GoGame.java:59-126
+class GoGame : public Game {
+public:
+    using Game::Game;
+    using Game::getObservationModelInput;
+    bool terminal() const override;
+    const OneOfTwoPlayer* toPlay() const override;
+    ObservationModelInput getObservationModelInput(int inputTime) const override;
+    void connectToEnvironment() override;
+};
+
+// ---- random sources --------------------------------------------------------------------------
+// Stand-in for ThreadLocalRandom / SSJ DirichletGen (GumbelFunctions.java:48-54, Functions.java:28-37,
+// 128-138): noise is an INPUT of the device path, so only its distribution matters.  SplitMix64 so
+// that a Python test can regenerate the same stream.
+struct Rng {
+    uint64_t state;
+    explicit Rng(uint64_t seed) : state(seed) {}
+    uint64_t next();
+    double nextDouble();                       // [0,1)
+    int nextInt(int origin, int bound);        // [origin, bound)
+    double drawGumble();                       // -log(-log(u)), u != 0
+    double nextGaussian();
+    double nextGamma(double alpha);
+    void dirichlet(double alpha, int dims, double* out);
+};
+
+// ---- inference level -------------------------------------------------------------------------
+// P/agent/d_model/NetworkIO.java:39-52; hiddenState is a slot of the context's HBM pool
+struct NetworkIO {
+    std::vector<float> logits, policyValues;
+    double value = 0;
+    int hiddenState = -1;
+};
+
+// P/agent/d_model/service/ModelService.java:34-67,137-175 + ModelController.java:119-152 (model load)
+class ModelService {
+public:
+    ModelService(const MuZeroConfig& config, int maxGames, int precision, int device, int poolSlots = 0);
+    ~ModelService();
+    ModelService(const ModelService&) = delete;
+    ModelService& operator=(const ModelService&) = delete;
+
+    void loadWeights(const float* blob, size_t count);  // ModelController.loadModel
+    NetworkIO initialInference(const Game& game);
+    std::vector<NetworkIO> initialInference(const std::vector<const Game*>& games);
+    // ModelService.recurrentInference(NDArray hiddenState, int action): parent slot + action -> new slot
+    std::vector<NetworkIO> recurrentInference(const std::vector<int>& hiddenStates, const std::vector<int>& actions);
+    void startScope() { nextSlot = 0; }  // ModelController.java:156-166: hidden states live per playGames call
+    void endScope() { nextSlot = 0; }
+    mz_ctx* native() { return ctx; }
+    const MuZeroConfig& getConfig() const { return config; }
+    int maxGames() const { return maxGames_; }
+
+private:
+    void check(int rc, const char* what);
+    MuZeroConfig config;
+    mz_ctx* ctx = nullptr;
+    int maxGames_, poolSlots, nextSlot = 0;
+};
+
+// P/agent/b_episode/PlayParameters.java:8-33
+struct PlayParameters {
+    bool render = true;
+    bool fastRulesLearning = false;
+    bool untilEnd = true;
+    bool justInitialInferencePolicy = false;
+    bool justReplayWithInitialReference = false;
+    bool withGumbel = true;
+    int averageGameLength = 0;
+    double pRandomActionRawAverage = 0;
+    bool replay = false;
+};
+
+// P/agent/c_planning/PlanAction.java:68-171, batched: one planned move for every game of `games`.
+class PlanAction {
+public:
+    PlanAction(ModelService& modelService, uint64_t seed) : modelService(modelService), rng(seed) {}
+    // Returns the chosen action per game and appends to each GameDTO what planAction +
+    // storeSearchStatistics + selectAction append.
+    std::vector<Action> planActions(const std::vector<Game*>& games, const PlayParameters& p);
+    // PlanAction.java:34-65
+    void justReplayActionsWithInitialInference(const std::vector<Game*>& games);
+    int64_t simulationsRun = 0;
+
+private:
+    ModelService& modelService;
+    Rng rng;
+};
+
+// P/agent/a_loopcontrol/parallelEpisodes/PlayService.java:39-146 (+ SelfPlayGame.play, b_episode/SelfPlayGame.java:26-68)
+class PlayService {
+public:
+    PlayService(ModelService& modelService, uint64_t seed) : modelService(modelService), planAction(modelService, seed), rng(seed ^ 0x9E3779B97F4A7C15ull) {}
+    std::vector<std::unique_ptr<Game>> playNewGames(int numGames, PlayParameters p);
+    void playGames(const std::vector<Game*>& games, PlayParameters p);
+    void reanalyseGames(const std::vector<Game*>& games, PlayParameters p);            // PlayService.java:53-76
+    void justReplayGamesWithInitialInference(const std::vector<Game*>& games);         // :78-85
+    void hybridConfiguration(const std::vector<Game*>& games, int gameLength);         // :92-103
+    int maxGameLength = 0;  // gameBuffer.getMaxGameLength()
+    int64_t simulationsRun() const { return planAction.simulationsRun; }
+
+private:
+    ModelService& modelService;
+    PlanAction planAction;
+    Rng rng;
+};
+
+}  // namespace muzero
