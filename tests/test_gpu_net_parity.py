@@ -104,7 +104,7 @@ def test_weight_blob_size_is_checked():
     ctx.close()
 
 
-@pytest.mark.parametrize("name", ["go9", "pegsolitair"])
+@pytest.mark.parametrize("name", ["go9", "pegsolitair", "tictactoe", "go5"])
 def test_bf16_mfma_forward_matches_oracle(name):
     # B=7: two workgroup tiles for Go 9x9 (3 boards each) plus a ragged last tile
     _check(_specs()[name], capi.PRECISION_BF16, B=7, seed=3)
