@@ -59,6 +59,17 @@ constexpr int SMAX = 32;     // fragments (KiB) per ring slot
 constexpr int MAXNB = 32;    // boards per workgroup upper bound (256 / 9 = 28)
 constexpr int ZROW_BYTES = 1024;
 
+#if defined(MZ_STAMPS)  // diagnostic build: per-phase cycle counts of workgroup 0 (waves 0 and 7), printed by the kernel
+#define STAMP(c, i) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); (c).st_acc[i] += (unsigned)(t_ - (c).st_last); (c).st_last = t_; } while (0)
+#define STAMP_PRINT(c, name) do { if (blockIdx.x == 0 && ((c).wave == 0 || (c).wave == 7) && (c).lane == 0) \
+    printf("%s w%d: stats %u norm %u acquire %u mma %u xload %u xstore %u rescale %u head %u other %u bcast %u | hconv %u hln %u hfc %u\n", name, (c).wave, \
+           (c).st_acc[0], (c).st_acc[1], (c).st_acc[2], (c).st_acc[3], (c).st_acc[4], (c).st_acc[5], (c).st_acc[6], (c).st_acc[7], (c).st_acc[8], (c).st_acc[9], (c).st_acc[10], (c).st_acc[11], (c).st_acc[12]); } while (0)
+#else
+#define STAMP(c, i)
+#define STAMP_PRINT(c, name)
+#endif
+enum { ST_STATS = 0, ST_NORM, ST_ACQ, ST_MMA, ST_XLOAD, ST_XSTORE, ST_RESCALE, ST_HEAD, ST_OTHER, ST_BCAST, ST_HCONV, ST_HLN, ST_HFC };
+
 enum { IN_OBS = 0, IN_HIDDEN = 1, IN_X = 2 };
 enum { OUT_X = 0, OUT_FINAL = 1 };
 
@@ -145,6 +156,10 @@ struct Ctx {
     float* wpart;    // [2][MAXNB][8 waves][2] per-wave board partials (double buffered)
     int parity;
     int* meta;       // [4][MAXNB]: src slot, dst slot, live, action cell
+#if defined(MZ_STAMPS)
+    unsigned st_acc[14];
+    unsigned long long st_last;
+#endif
 };
 
 // Two-slot LDS ring over the linear A-fragment stream, filled by LDS-DMA.  Protocol (all waves):
@@ -350,7 +365,9 @@ __device__ __forceinline__ void ln_to_image(Ctx& c, const Col& k, const u32x4* g
     u32x4 g[2][4];
     gb_load(gb, c, k, c.wr * NR, g[0]);   // requested before the statistics round trip
     float mean, rstd;
+    STAMP(c, ST_OTHER);
     ln_stats<NR>(c, k, v, nch, mean, rstd);
+    STAMP(c, ST_STATS);
     const float nmr = -mean * rstd;
 #pragma unroll
     for (int rt = 0; rt < NR; rt++) {
@@ -359,6 +376,7 @@ __device__ __forceinline__ void ln_to_image(Ctx& c, const Col& k, const u32x4* g
         ln_apply_pk(v[rt], rstd, nmr, g[rt & 1], o);   // padded columns: gamma = beta = 0 -> zeros
         img_store_pk(img, rs, k.col, c.wr * NR + rt, c.h, o);
     }
+    STAMP(c, ST_NORM);
 }
 
 // acc[ro] += conv(image) for this wave's NROW output row tiles (of NROT in the layer).
@@ -374,7 +392,9 @@ __device__ __forceinline__ void conv_lds(Ctx& c, const Col& k, WRing& ring, f32x
 #pragma unroll
     for (int kk = 0; kk < KK; kk++) {
         if (kk % SK == 0) {
+            STAMP(c, kk == 0 ? ST_OTHER : ST_MMA);
             slot = ring.acquire() + (c.wr * NROW) * 1024 + c.lane * 16;
+            STAMP(c, ST_ACQ);
             const int rem = KK - (kk + SK);
             const int nfn = rem > 0 ? (rem < SK ? rem : SK) * NROT : next_nf;
             ring.issue(nfn);
@@ -395,6 +415,7 @@ __device__ __forceinline__ void conv_lds(Ctx& c, const Col& k, WRing& ring, f32x
             acc[ro] = MFMA(a, b, acc[ro]);
         }
     }
+    STAMP(c, ST_MMA);
 }
 
 template <int NR>
@@ -490,6 +511,10 @@ __device__ __forceinline__ void ctx_init(Ctx& c, char* smem, const LdsPlan& L, c
     c.wpart = reinterpret_cast<float*>(smem + L.stat_off);
     c.parity = 0;
     c.meta = reinterpret_cast<int*>(smem + L.meta_off);
+#if defined(MZ_STAMPS)
+    for (int i = 0; i < 14; i++) c.st_acc[i] = 0;
+    c.st_last = __builtin_amdgcn_s_memtime();
+#endif
 }
 
 // X <-> [slot][C][HW] fp32 in the hidden-state pool (slot index from meta row `which`); this wave's row tiles.
@@ -545,6 +570,7 @@ __global__ __launch_bounds__(NT) void k_seg(NetDims d, TowerDev tw, HeadDev hd, 
         ring.init(tw.stream + (long long)tw.foff[b0] * 64, smem + L.ring_off, c.wave, c.lane);
         if (b0 < b1) ring.issue(FS_C1);
         x_load<NRCW>(c, k, io.pool, 1, C, X);
+        STAMP(c, ST_XLOAD);
     } else {
         ring.init(tw.stream, smem + L.ring_off, c.wave, c.lane);
         ring.issue(first_stage_frags(9 * KS0, G::NRC));
@@ -593,9 +619,13 @@ __global__ __launch_bounds__(NT) void k_seg(NetDims d, TowerDev tw, HeadDev hd, 
     }
 
     if (OUT == OUT_X) {
+        STAMP(c, ST_OTHER);
         x_store<NRCW>(c, k, io.pool, C, X);
+        STAMP(c, ST_XSTORE);
+        STAMP_PRINT(c, "seg");
         return;
     }
+    STAMP(c, ST_OTHER);
     // ---------------- RescaleBlockExt + hidden-state store ----------------
     {
         float mn = INFINITY, mx = -INFINITY;
@@ -616,7 +646,9 @@ __global__ __launch_bounds__(NT) void k_seg(NetDims d, TowerDev tw, HeadDev hd, 
         for (int rt = 0; rt < NRCW; rt++)
 #pragma unroll
             for (int i = 0; i < 16; i++) X[rt][i] = (X[rt][i] - mn) / dd;
+        STAMP(c, ST_RESCALE);
         x_store<NRCW>(c, k, io.pool, C, X);
+        STAMP(c, ST_XSTORE);
     }
     // ---------------- PredictionBlock ----------------
     // 1x1 convs C -> {policy 0, policy 1, value} in fp32 on the VALU (3 output rows only): the per-board
@@ -629,6 +661,39 @@ __global__ __launch_bounds__(NT) void k_seg(NetDims d, TowerDev tw, HeadDev hd, 
     float* hv = lgt + MAXNB * A;               // [NB][C]
     float* hwl = hv + MAXNB * C;               // [3][C] head conv weights
     float* hpart = hwl + 3 * C;                // [2*WR][COLS][4] partial dot products
+    float* part1 = hpart + 2 * WR * G::COLS * 4;   // [n1][NB*A] K-chunk partials of the policy linear
+    constexpr int KC = 32;                     // K-chunk of the head linears
+    const int K1 = 2 * HW, n1 = (K1 + KC - 1) / KC, n2 = (HW + KC - 1) / KC;
+    const int items1 = n1 * A, items2 = n2 * C;   // work items (K chunk, output) of the two linears
+    float* part2 = part1 + items1 * NB;        // [n2][NB*C] K-chunk partials of the first value linear
+    // An item = one output of one K chunk for all boards.  The weights of each thread's first item are
+    // requested here, long before the features exist, so their latency hides behind the head convs.
+    struct FcItem {
+        const float* w;
+        const float* f;
+        float* out;
+        int nout, kn, fstride;
+    };
+    auto fc_item = [&](int it) {
+        const bool pol = it < items1;
+        const int j = pol ? it : it - items1;
+        const int nout = pol ? A : C, K = pol ? K1 : HW;
+        const int ck = j / nout, o = j - ck * nout;
+        FcItem r;
+        r.w = (pol ? hd.pfcw : hd.vfc1w) + (long long)(ck * KC) * nout + o;
+        r.f = (pol ? pfeat : vfeat) + ck * KC;
+        r.out = (pol ? part1 : part2) + ck * NB * nout + o;
+        r.nout = nout;
+        r.kn = K - ck * KC;
+        r.fstride = K;
+        return r;
+    };
+    float wv[KC];
+    if (tid < items1 + items2) {
+        const FcItem q = fc_item(tid);
+#pragma unroll
+        for (int i = 0; i < KC; i++) wv[i] = i < q.kn ? q.w[(long long)i * q.nout] : 0.f;
+    }
     for (int i = tid; i < 3 * C; i += NT) hwl[i] = hd.hconv[i];
     lds_barrier();
     {
@@ -636,12 +701,18 @@ __global__ __launch_bounds__(NT) void k_seg(NetDims d, TowerDev tw, HeadDev hd, 
 #pragma unroll
         for (int rt = 0; rt < NRCW; rt++)
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const int ch = 32 * (c.wr * NRCW + rt) + (i & 3) + 8 * (i >> 2) + 4 * c.h;
-                const float x = X[rt][i];
-                p0 = fmaf(x, hwl[ch], p0);
-                p1 = fmaf(x, hwl[C + ch], p1);
-                v = fmaf(x, hwl[2 * C + ch], v);
+            for (int qd = 0; qd < 4; qd++) {
+                const int ch = 32 * (c.wr * NRCW + rt) + 8 * qd + 4 * c.h;
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(hwl + ch);
+                const f32x4 w1 = *reinterpret_cast<const f32x4*>(hwl + C + ch);
+                const f32x4 w2 = *reinterpret_cast<const f32x4*>(hwl + 2 * C + ch);
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float x = X[rt][4 * qd + e];
+                    p0 = fmaf(x, w0[e], p0);
+                    p1 = fmaf(x, w1[e], p1);
+                    v = fmaf(x, w2[e], v);
+                }
             }
         float* hp = hpart + ((c.wr * 2 + c.h) * G::COLS + k.col) * 4;
         hp[0] = p0;
@@ -649,6 +720,7 @@ __global__ __launch_bounds__(NT) void k_seg(NetDims d, TowerDev tw, HeadDev hd, 
         hp[2] = v;
     }
     lds_barrier();
+    STAMP(c, ST_HCONV);
     {
         // policy LN over (2, HW), value LN over (1, HW); one lane per column does the work
         const bool own = k.valid && c.h == 0 && c.wr == 0;
@@ -675,21 +747,36 @@ __global__ __launch_bounds__(NT) void k_seg(NetDims d, TowerDev tw, HeadDev hd, 
         }
     }
     lds_barrier();
+    STAMP(c, ST_HLN);
+    // The two linears, split over K into chunks of KC so that every thread has work and each item's weight
+    // loads are independent (all in flight at once); the chunk partials are summed in a fixed order.
+    for (int it = tid; it < items1 + items2; it += NT) {
+        const FcItem q = fc_item(it);
+        if (it != tid) {
+#pragma unroll
+            for (int i = 0; i < KC; i++) wv[i] = i < q.kn ? q.w[(long long)i * q.nout] : 0.f;
+        }
+        for (int bd = 0; bd < NB; bd++) {
+            const float* f = q.f + bd * q.fstride;
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < KC; i++) acc = fmaf(i < q.kn ? f[i] : 0.f, wv[i], acc);
+            q.out[bd * q.nout] = acc;
+        }
+    }
+    lds_barrier();
     for (int idx = tid; idx < NB * A; idx += NT) {
-        const int bd = idx / A, a = idx - bd * A;
-        float acc = hd.pfcb[a];
-        const float* f = pfeat + bd * 2 * HW;
-        for (int i = 0; i < 2 * HW; i++) acc = fmaf(f[i], hd.pfcw[(long long)i * A + a], acc);
+        float acc = hd.pfcb[idx % A];
+        for (int ck = 0; ck < n1; ck++) acc += part1[ck * NB * A + idx];
         lgt[idx] = acc;
     }
     for (int idx = tid; idx < NB * C; idx += NT) {
-        const int bd = idx / C, ch = idx - bd * C;
-        float acc = hd.vfc1b[ch];
-        const float* f = vfeat + bd * HW;
-        for (int p = 0; p < HW; p++) acc = fmaf(f[p], hd.vfc1w[(long long)p * C + ch], acc);
+        float acc = hd.vfc1b[idx % C];
+        for (int ck = 0; ck < n2; ck++) acc += part2[ck * NB * C + idx];
         hv[idx] = fmaxf(acc, 0.f);
     }
     lds_barrier();
+    STAMP(c, ST_HFC);
     for (int bd = c.wave; bd < NB; bd += NWAVE) {
         if (!c.meta[2 * MAXNB + bd]) continue;
         const int g = g0 + bd;
@@ -713,6 +800,8 @@ __global__ __launch_bounds__(NT) void k_seg(NetDims d, TowerDev tw, HeadDev hd, 
             io.value[g] = d.value_scale * (double)v;
         }
     }
+    STAMP(c, ST_HEAD);
+    STAMP_PRINT(c, "seg+heads");
 }
 
 // ---- BroadcastResidualBlock: x + c2(relu(LN(bcast(relu(LN(c1(relu(LN(x))))))))) ------------------
@@ -749,6 +838,7 @@ __global__ __launch_bounds__(NT) void k_bcast(NetDims d, TowerDev tw, NetIO io, 
         ln_to_image<NRCW>(c, k, gb1, X, C, RS);
         zero_acc<NRCW>(a);
         conv_lds<KSC, 1, NRC, NRCW, RS>(c, k, ring, a, 0);
+        STAMP(c, ST_OTHER);
         // LN2 + ReLU -> bf16 -> transposed image TB (the statistics barrier proves that every wave has
         // finished c1, so the ring under TB is dead)
         u32x4 g[4];
@@ -856,10 +946,13 @@ __global__ __launch_bounds__(NT) void k_bcast(NetDims d, TowerDev tw, NetIO io, 
         }
     }
     lds_barrier();   // image complete, TB dead: region 2 is the ring again
+    STAMP(c, ST_BCAST);
     // c2: 1x1 conv C -> C on the image (own columns), accumulated into X
     ring.issue(FS);
     conv_lds<KSC, 1, NRC, NRCW, RS>(c, k, ring, X, 0);
     x_store<NRCW>(c, k, io.pool, C, X);
+    STAMP(c, ST_XSTORE);
+    STAMP_PRINT(c, "bcast");
 }
 
 // ------------------------------- host side: packing -------------------------------------------
@@ -960,7 +1053,10 @@ LdsPlan make_plan_seg(const NetDims& d, int COLS, int WR) {
     L.ring_off = 0;
     L.img_off = 2 * SMAX * 1024;
     int end = L.img_off + align16(COLS * rs0);
-    const int head_need = (MAXNB * (3 * d.HW + d.A + d.C) + 3 * d.C + 2 * WR * COLS * 4) * 4;
+    int NB = COLS / d.HW;
+    if (NB > MAXNB) NB = MAXNB;
+    const int kchunks = ((2 * d.HW + 31) / 32 * d.A + (d.HW + 31) / 32 * d.C) * NB;   // K-chunk partials of the head linears
+    const int head_need = (MAXNB * (3 * d.HW + d.A + d.C) + 3 * d.C + 2 * WR * COLS * 4 + kchunks) * 4;
     if (head_need > end) end = head_need;
     L.head_off = 0;
     plan_tail(L, end);
