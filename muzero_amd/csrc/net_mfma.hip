@@ -362,18 +362,21 @@ template <int NR>
 __device__ __forceinline__ void ln_to_image(Ctx& c, const Col& k, const u32x4* gb, const f32x16 (&v)[NR], int nch,
                                             int rs) {
     char* img = c.smem + c.L.img_off;
-    u32x4 g[2][4];
-    gb_load(gb, c, k, c.wr * NR, g[0]);   // requested before the statistics round trip
+    u32x4 g[NR][4];
+    // the first two row tiles are requested before the statistics round trip, the rest right after it
+    gb_load(gb, c, k, c.wr * NR, g[0]);
+    if (NR > 1) gb_load(gb, c, k, c.wr * NR + 1, g[1]);
     float mean, rstd;
     STAMP(c, ST_OTHER);
     ln_stats<NR>(c, k, v, nch, mean, rstd);
     STAMP(c, ST_STATS);
+#pragma unroll
+    for (int rt = 2; rt < NR; rt++) gb_load(gb, c, k, c.wr * NR + rt, g[rt]);
     const float nmr = -mean * rstd;
 #pragma unroll
     for (int rt = 0; rt < NR; rt++) {
-        if (rt + 1 < NR) gb_load(gb, c, k, c.wr * NR + rt + 1, g[(rt + 1) & 1]);
         unsigned o[8];
-        ln_apply_pk(v[rt], rstd, nmr, g[rt & 1], o);   // padded columns: gamma = beta = 0 -> zeros
+        ln_apply_pk(v[rt], rstd, nmr, g[rt], o);   // padded columns: gamma = beta = 0 -> zeros
         img_store_pk(img, rs, k.col, c.wr * NR + rt, c.h, o);
     }
     STAMP(c, ST_NORM);
@@ -650,158 +653,166 @@ __global__ __launch_bounds__(NT) void k_seg(NetDims d, TowerDev tw, HeadDev hd, 
         x_store<NRCW>(c, k, io.pool, C, X);
         STAMP(c, ST_XSTORE);
     }
-    // ---------------- PredictionBlock ----------------
-    // 1x1 convs C -> {policy 0, policy 1, value} in fp32 on the VALU (3 output rows only): the per-board
-    // LayerNorm over a single HW-value channel that follows amplifies bf16 rounding, so these stay exact.
-    // (every wave has passed the rescale barrier, so the image and the ring are dead: reuse as scratch)
-    float* hs = reinterpret_cast<float*>(smem + L.head_off);
-    float* pfeat = hs;                         // [NB][2*HW]
-    float* vfeat = pfeat + MAXNB * 2 * HW;     // [NB][HW]
-    float* lgt = vfeat + MAXNB * HW;           // [NB][A]
-    float* hv = lgt + MAXNB * A;               // [NB][C]
-    float* hwl = hv + MAXNB * C;               // [3][C] head conv weights
-    float* hpart = hwl + 3 * C;                // [2*WR][COLS][4] partial dot products
-    float* part1 = hpart + 2 * WR * G::COLS * 4;   // [n1][NB*A] K-chunk partials of the policy linear
-    constexpr int KC = 32;                     // K-chunk of the head linears
-    const int K1 = 2 * HW, n1 = (K1 + KC - 1) / KC, n2 = (HW + KC - 1) / KC;
-    const int items1 = n1 * A, items2 = n2 * C;   // work items (K chunk, output) of the two linears
-    float* part2 = part1 + items1 * NB;        // [n2][NB*C] K-chunk partials of the first value linear
-    // An item = one output of one K chunk for all boards.  The weights of each thread's first item are
-    // requested here, long before the features exist, so their latency hides behind the head convs.
-    struct FcItem {
+    STAMP_PRINT(c, "seg+rescale");
+}
+
+// ---- PredictionBlock (B/c_mainfunctions/PredictionBlock.java:46-84) ------------------------------
+// One 256-thread workgroup per sample, many workgroups per CU: the heads are small latency chains
+// (1x1 convs -> LayerNorm -> linears -> softmax / tanh), so they run at high occupancy off the freshly
+// written hidden state instead of serialising the big workgroups of the tower kernels.  All fp32: the
+// per-board LayerNorm over a single HW-value channel amplifies rounding of whatever feeds it.
+constexpr int HT = 256;      // threads
+constexpr int HKC = 32;      // K chunk of the two linears
+constexpr int HPMAX = 128;   // cells per sample upper bound (HW <= 96)
+__global__ __launch_bounds__(HT) void k_heads(NetDims d, HeadDev hd, NetIO io) {
+    const int g = blockIdx.x;
+    if (g >= io.B || (io.active && !io.active[g])) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int HW = d.HW, C = d.C, A = d.A;
+    extern __shared__ __attribute__((aligned(16))) char hsm[];
+    float* red = reinterpret_cast<float*>(hsm);   // [4 waves][3][HPMAX] partial head-conv outputs
+    float* feat = red + 4 * 3 * HPMAX;            // policy features [2*HW], then value features [HW]
+    float* stat = feat + 3 * HPMAX;               // [8..15]: wave partials of the LayerNorm sums
+    float* lgt = stat + 32;                       // [A]
+    float* hv = lgt + A;                          // [C]
+    float* part = hv + C;                         // K-chunk partials: [n1][A] then [n2][C]
+    const int K1 = 2 * HW, n1 = (K1 + HKC - 1) / HKC, n2 = (HW + HKC - 1) / HKC;
+    const int items1 = n1 * A, items = items1 + n2 * C;
+    const float* h = io.pool + (long long)io.dst_slot[g] * C * HW;
+
+    // weights of this thread's first linear item: requested before anything else
+    struct Item {
         const float* w;
         const float* f;
-        float* out;
-        int nout, kn, fstride;
+        int nout, kn;
     };
-    auto fc_item = [&](int it) {
+    auto item = [&](int it) {
         const bool pol = it < items1;
         const int j = pol ? it : it - items1;
         const int nout = pol ? A : C, K = pol ? K1 : HW;
         const int ck = j / nout, o = j - ck * nout;
-        FcItem r;
-        r.w = (pol ? hd.pfcw : hd.vfc1w) + (long long)(ck * KC) * nout + o;
-        r.f = (pol ? pfeat : vfeat) + ck * KC;
-        r.out = (pol ? part1 : part2) + ck * NB * nout + o;
+        Item r;
+        r.w = (pol ? hd.pfcw : hd.vfc1w) + (long long)(ck * HKC) * nout + o;
+        r.f = (pol ? feat : feat + K1) + ck * HKC;
         r.nout = nout;
-        r.kn = K - ck * KC;
-        r.fstride = K;
+        r.kn = K - ck * HKC;
         return r;
     };
-    float wv[KC];
-    if (tid < items1 + items2) {
-        const FcItem q = fc_item(tid);
+    float wv[HKC];
+    if (tid < items) {
+        const Item q = item(tid);
 #pragma unroll
-        for (int i = 0; i < KC; i++) wv[i] = i < q.kn ? q.w[(long long)i * q.nout] : 0.f;
+        for (int i = 0; i < HKC; i++) wv[i] = i < q.kn ? q.w[(long long)i * q.nout] : 0.f;
     }
-    for (int i = tid; i < 3 * C; i += NT) hwl[i] = hd.hconv[i];
-    lds_barrier();
+    // 1x1 convs C -> {policy 0, policy 1, value}: wave w takes channels w, w+4, ...; lane l the cells l, l+64
     {
-        float p0 = 0.f, p1 = 0.f, v = 0.f;
-#pragma unroll
-        for (int rt = 0; rt < NRCW; rt++)
-#pragma unroll
-            for (int qd = 0; qd < 4; qd++) {
-                const int ch = 32 * (c.wr * NRCW + rt) + 8 * qd + 4 * c.h;
-                const f32x4 w0 = *reinterpret_cast<const f32x4*>(hwl + ch);
-                const f32x4 w1 = *reinterpret_cast<const f32x4*>(hwl + C + ch);
-                const f32x4 w2 = *reinterpret_cast<const f32x4*>(hwl + 2 * C + ch);
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const float x = X[rt][4 * qd + e];
-                    p0 = fmaf(x, w0[e], p0);
-                    p1 = fmaf(x, w1[e], p1);
-                    v = fmaf(x, w2[e], v);
-                }
-            }
-        float* hp = hpart + ((c.wr * 2 + c.h) * G::COLS + k.col) * 4;
-        hp[0] = p0;
-        hp[1] = p1;
-        hp[2] = v;
-    }
-    lds_barrier();
-    STAMP(c, ST_HCONV);
-    {
-        // policy LN over (2, HW), value LN over (1, HW); one lane per column does the work
-        const bool own = k.valid && c.h == 0 && c.wr == 0;
-        float hp0 = 0.f, hp1 = 0.f, hvv = 0.f;
-#pragma unroll
-        for (int j = 0; j < 2 * WR; j++) {
-            const float* hp = hpart + (j * G::COLS + k.col) * 4;
-            hp0 += hp[0];
-            hp1 += hp[1];
-            hvv += hp[2];
+        float a00 = 0.f, a01 = 0.f, a02 = 0.f, a10 = 0.f, a11 = 0.f, a12 = 0.f;
+        const bool v0 = lane < HW, v1 = lane + 64 < HW;
+        const float* h0 = h + (v0 ? lane : 0);
+        const float* h1 = h + (v1 ? lane + 64 : 0);
+#pragma unroll 8
+        for (int ch = wave; ch < C; ch += 4) {
+            const float x0 = h0[ch * HW], x1 = h1[ch * HW];
+            const float w0 = hd.hconv[ch], w1 = hd.hconv[C + ch], w2 = hd.hconv[2 * C + ch];
+            a00 = fmaf(x0, w0, a00);
+            a01 = fmaf(x0, w1, a01);
+            a02 = fmaf(x0, w2, a02);
+            a10 = fmaf(x1, w0, a10);
+            a11 = fmaf(x1, w1, a11);
+            a12 = fmaf(x1, w2, a12);
         }
-        float s = own ? hp0 + hp1 : 0.f, q = own ? hp0 * hp0 + hp1 * hp1 : 0.f;
-        float vs = own ? hvv : 0.f, vq = own ? hvv * hvv : 0.f;
-        board_reduce<0>(c, k, s, q, 1.0f / (float)(2 * HW));
-        board_reduce<0>(c, k, vs, vq, 1.0f / (float)HW);
-        if (own) {
-            const int bd = k.board, p = k.p;
-            float t0 = (hp0 - s) * q * hd.plng[p] + hd.plnb[p];
-            float t1 = (hp1 - s) * q * hd.plng[HW + p] + hd.plnb[HW + p];
-            pfeat[bd * 2 * HW + p] = fmaxf(t0, 0.f);
-            pfeat[bd * 2 * HW + HW + p] = fmaxf(t1, 0.f);
-            float t = (hvv - vs) * vq * hd.vlng[p] + hd.vlnb[p];
-            vfeat[bd * HW + p] = fmaxf(t, 0.f);
+        float* r = red + wave * 3 * HPMAX;
+        r[lane] = a00;
+        r[HPMAX + lane] = a01;
+        r[2 * HPMAX + lane] = a02;
+        r[64 + lane] = a10;
+        r[HPMAX + 64 + lane] = a11;
+        r[2 * HPMAX + 64 + lane] = a12;
+    }
+    __syncthreads();
+    // LayerNorm over (2, HW) for the policy features and over (1, HW) for the value features
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    const bool own = tid < HW;   // waves 0 and 1
+    if (tid < HPMAX) {
+        for (int w = 0; w < 4; w++) {
+            c0 += red[w * 3 * HPMAX + tid];
+            c1 += red[w * 3 * HPMAX + HPMAX + tid];
+            c2 += red[w * 3 * HPMAX + 2 * HPMAX + tid];
+        }
+        float s = own ? c0 + c1 : 0.f, q = own ? c0 * c0 + c1 * c1 : 0.f;
+        float vs = own ? c2 : 0.f, vq = own ? c2 * c2 : 0.f;
+        s = wave_red<0>(s);
+        q = wave_red<0>(q);
+        vs = wave_red<0>(vs);
+        vq = wave_red<0>(vq);
+        if (lane == 0) {
+            stat[8 + 4 * wave] = s;
+            stat[9 + 4 * wave] = q;
+            stat[10 + 4 * wave] = vs;
+            stat[11 + 4 * wave] = vq;
         }
     }
-    lds_barrier();
-    STAMP(c, ST_HLN);
-    // The two linears, split over K into chunks of KC so that every thread has work and each item's weight
-    // loads are independent (all in flight at once); the chunk partials are summed in a fixed order.
-    for (int it = tid; it < items1 + items2; it += NT) {
-        const FcItem q = fc_item(it);
+    __syncthreads();
+    if (own) {
+        const float s = stat[8] + stat[12], q = stat[9] + stat[13], vs = stat[10] + stat[14], vq = stat[11] + stat[15];
+        const float pm = s / (float)(2 * HW), pr = __builtin_amdgcn_rsqf(fmaxf(q / (float)(2 * HW) - pm * pm, 0.f) + 1e-5f);
+        const float vm = vs / (float)HW, vr = __builtin_amdgcn_rsqf(fmaxf(vq / (float)HW - vm * vm, 0.f) + 1e-5f);
+        const int p = tid;
+        feat[p] = fmaxf((c0 - pm) * pr * hd.plng[p] + hd.plnb[p], 0.f);
+        feat[HW + p] = fmaxf((c1 - pm) * pr * hd.plng[HW + p] + hd.plnb[HW + p], 0.f);
+        feat[K1 + p] = fmaxf((c2 - vm) * vr * hd.vlng[p] + hd.vlnb[p], 0.f);
+    }
+    __syncthreads();
+    // the two linears, split over K into chunks of HKC; chunk partials are summed in a fixed order
+    for (int it = tid; it < items; it += HT) {
+        const Item q = item(it);
         if (it != tid) {
 #pragma unroll
-            for (int i = 0; i < KC; i++) wv[i] = i < q.kn ? q.w[(long long)i * q.nout] : 0.f;
+            for (int i = 0; i < HKC; i++) wv[i] = i < q.kn ? q.w[(long long)i * q.nout] : 0.f;
         }
-        for (int bd = 0; bd < NB; bd++) {
-            const float* f = q.f + bd * q.fstride;
-            float acc = 0.f;
+        float acc = 0.f;
 #pragma unroll
-            for (int i = 0; i < KC; i++) acc = fmaf(i < q.kn ? f[i] : 0.f, wv[i], acc);
-            q.out[bd * q.nout] = acc;
-        }
+        for (int i = 0; i < HKC; i++) acc = fmaf(i < q.kn ? q.f[i] : 0.f, wv[i], acc);
+        part[it] = acc;
     }
-    lds_barrier();
-    for (int idx = tid; idx < NB * A; idx += NT) {
-        float acc = hd.pfcb[idx % A];
-        for (int ck = 0; ck < n1; ck++) acc += part1[ck * NB * A + idx];
-        lgt[idx] = acc;
+    __syncthreads();
+    for (int a = tid; a < A; a += HT) {
+        float acc = hd.pfcb[a];
+        for (int ck = 0; ck < n1; ck++) acc += part[ck * A + a];
+        lgt[a] = acc;
     }
-    for (int idx = tid; idx < NB * C; idx += NT) {
-        float acc = hd.vfc1b[idx % C];
-        for (int ck = 0; ck < n2; ck++) acc += part2[ck * NB * C + idx];
-        hv[idx] = fmaxf(acc, 0.f);
+    for (int ch = tid; ch < C; ch += HT) {
+        float acc = hd.vfc1b[ch];
+        for (int ck = 0; ck < n2; ck++) acc += part[items1 + ck * C + ch];
+        hv[ch] = fmaxf(acc, 0.f);
     }
-    lds_barrier();
-    STAMP(c, ST_HFC);
-    for (int bd = c.wave; bd < NB; bd += NWAVE) {
-        if (!c.meta[2 * MAXNB + bd]) continue;
-        const int g = g0 + bd;
-        float part = 0.f;
-        for (int ch = c.lane; ch < C; ch += 64) part = fmaf(hv[bd * C + ch], hd.vfc2w[ch], part);
+    __syncthreads();
+    if (wave == 0) {
         float mx = -INFINITY;
-        for (int a = c.lane; a < A; a += 64) mx = fmaxf(mx, lgt[bd * A + a]);
-        part = wave_red<0>(part);
+        for (int a = lane; a < A; a += 64) mx = fmaxf(mx, lgt[a]);
         mx = wave_red<2>(mx);
         float se = 0.f;
-        for (int a = c.lane; a < A; a += 64) se += expf(lgt[bd * A + a] - mx);
+        for (int a = lane; a < A; a += 64) se += expf(lgt[a] - mx);
         se = wave_red<0>(se);
-        for (int a = c.lane; a < A; a += 64) {
-            const float l = lgt[bd * A + a];
+        for (int a = lane; a < A; a += 64) {
+            const float l = lgt[a];
             io.logits[(long long)g * A + a] = l;
             io.policy[(long long)g * A + a] = expf(l - mx) / se;
         }
-        if (c.lane == 0) {
-            float v = part + hd.vfc2b[0];
+    } else if (wave == 1) {
+        float pv = 0.f;
+        for (int ch = lane; ch < C; ch += 64) pv = fmaf(hv[ch], hd.vfc2w[ch], pv);
+        pv = wave_red<0>(pv);
+        if (lane == 0) {
+            float v = pv + hd.vfc2b[0];
             if (d.two_players) v = tanhf(v);
             io.value[g] = d.value_scale * (double)v;
         }
     }
-    STAMP(c, ST_HEAD);
-    STAMP_PRINT(c, "seg+heads");
+}
+size_t heads_lds_bytes(const NetDims& d) {
+    const int n1 = (2 * d.HW + HKC - 1) / HKC, n2 = (d.HW + HKC - 1) / HKC;
+    return (size_t)(4 * 3 * HPMAX + 3 * HPMAX + 32 + d.A + d.C + n1 * d.A + n2 * d.C) * 4;
 }
 
 // ---- BroadcastResidualBlock: x + c2(relu(LN(bcast(relu(LN(c1(relu(LN(x))))))))) ------------------
@@ -1045,7 +1056,7 @@ void plan_tail(LdsPlan& L, int end) {
     L.total = align16(end);
 }
 
-// k_seg: [ring][image]; the head scratch reuses both once the tower is done
+// k_seg: [ring][image]
 LdsPlan make_plan_seg(const NetDims& d, int COLS, int WR) {
     LdsPlan L{};
     const int rs0 = (d.C + 16) * 2 + 16;
@@ -1053,11 +1064,6 @@ LdsPlan make_plan_seg(const NetDims& d, int COLS, int WR) {
     L.ring_off = 0;
     L.img_off = 2 * SMAX * 1024;
     int end = L.img_off + align16(COLS * rs0);
-    int NB = COLS / d.HW;
-    if (NB > MAXNB) NB = MAXNB;
-    const int kchunks = ((2 * d.HW + 31) / 32 * d.A + (d.HW + 31) / 32 * d.C) * NB;   // K-chunk partials of the head linears
-    const int head_need = (MAXNB * (3 * d.HW + d.A + d.C) + 3 * d.C + 2 * WR * COLS * 4 + kchunks) * 4;
-    if (head_need > end) end = head_need;
     L.head_off = 0;
     plan_tail(L, end);
     return L;
@@ -1285,6 +1291,7 @@ int forward_t(MfmaNet* n, hipStream_t st, bool initial, const NetDims& d, const 
             if (last) launch_seg<G, IN_X, OUT_FINAL>(n, st, grid, d, tw, io, b, e);
             else launch_seg<G, IN_X, OUT_X>(n, st, grid, d, tw, io, b, e);
         }
+        if (last) hipLaunchKernelGGL(k_heads, dim3(io.B), dim3(HT), heads_lds_bytes(d), st, d, n->hd, io);
         first = false;
         if (last || (dbg_stop >= 0 && dbg_stop == e)) break;
         static bool bc_attr = false;
