@@ -53,9 +53,6 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) short s16x2;
 
-constexpr int NT = 512;      // threads per workgroup
-constexpr int NWAVE = 8;
-constexpr int SMAX = 32;     // fragments (KiB) per ring slot
 constexpr int MAXNB = 32;    // boards per workgroup upper bound (256 / 9 = 28)
 constexpr int ZROW_BYTES = 1024;
 
@@ -104,23 +101,27 @@ struct LdsPlan {
     int kp, qt;
 };
 
-template <int C_, int CB_, int WR_>
+// Workgroup geometry: NW waves as a WR x WC grid, ring slots of SM fragments (KiB), WPE = waves per SIMD the
+// register budget is cut for (2 workgroups of 6 waves per CU = 3 per SIMD, ...).
+template <int C_, int CB_, int WR_, int NW_, int SM_, int WPE_>
 struct Geo {
-    static constexpr int C = C_, CB = CB_, WR = WR_;
-    static constexpr int WC = NWAVE / WR, COLS = 32 * WC;
+    static constexpr int C = C_, CB = CB_, WR = WR_, NW = NW_, SM = SM_, WPE = WPE_;
+    static constexpr int NT = 64 * NW;
+    static constexpr int WC = NW / WR, COLS = 32 * WC;
+    static_assert(NW % WR == 0 && NW % 2 == 0, "wave grid");
     static constexpr int NRC = C / 32, NRB = CB / 32;       // row tiles of the whole layer
     static constexpr int NRCW = NRC / WR, NRBW = NRB / WR;  // row tiles one wave owns
     static_assert(NRC % WR == 0 && NRB % WR == 0 && NRBW >= 1, "channel split");
 };
 
-// Stage split of a conv with KK k-steps of NROT fragments: equal stages of SK k-steps, <= SMAX fragments.
-constexpr int stage_ksteps(int KK, int NROT) {
-    const int skmax = SMAX / NROT;
+// Stage split of a conv with KK k-steps of NROT fragments: equal stages of SK k-steps, <= SM fragments.
+constexpr int stage_ksteps(int KK, int NROT, int SM) {
+    const int skmax = SM / NROT;
     const int nst = (KK + skmax - 1) / skmax;
     return (KK + nst - 1) / nst;
 }
-constexpr int first_stage_frags(int KK, int NROT) {
-    const int sk = stage_ksteps(KK, NROT);
+constexpr int first_stage_frags(int KK, int NROT, int SM) {
+    const int sk = stage_ksteps(KK, NROT, SM);
     return (sk < KK ? sk : KK) * NROT;
 }
 
@@ -166,6 +167,7 @@ struct Ctx {
 //   issue(S0);  acquire() -> issue(S1) -> compute S0;  acquire() -> issue(S2) -> compute S1; ...
 // acquire() waits for this wave's own DMA of the stage, then the workgroup barrier makes every wave's
 // part visible and proves that all waves have left the slot the next issue() overwrites.
+template <int NW, int SM>
 struct WRing {
     const char* gptr;  // next fragment to load (wave-uniform)
     char* lds;         // ring base
@@ -180,10 +182,10 @@ struct WRing {
     }
     __device__ __forceinline__ void issue(int nf) {
         if (nf == 0) return;   // nothing follows: the slot parity stays with the next real issue()
-        char* dst = lds + ld_par * (SMAX * 1024);
+        char* dst = lds + ld_par * (SM * 1024);
 #pragma unroll
-        for (int i = 0; i < SMAX / NWAVE; i++) {
-            const int f = wave + NWAVE * i;
+        for (int i = 0; i < (SM + NW - 1) / NW; i++) {
+            const int f = wave + NW * i;
             if (f < nf)
                 __builtin_amdgcn_global_load_lds(
                     (const __attribute__((address_space(1))) void*)(gptr + (size_t)f * 1024 + lane16),
@@ -194,7 +196,7 @@ struct WRing {
     }
     __device__ __forceinline__ const char* acquire() {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        const char* p = lds + rd_par * (SMAX * 1024);
+        const char* p = lds + rd_par * (SM * 1024);
         rd_par ^= 1;
         return p;
     }
@@ -227,7 +229,7 @@ __device__ __forceinline__ float wave_red(float v) {
 // value; (2) lanes < NB publish wpart[parity][board][wave] (neutral where the wave holds none of the
 // board), barrier, and every lane combines the eight wave partials of its own board.  wpart alternates
 // between two buffers so the next reduction's writes cannot overtake this one's reads.
-template <int MODE>
+template <int MODE, int NW>
 __device__ __forceinline__ void board_reduce(Ctx& c, const Col& k, float& a, float& b, float n_inv) {
     const float na = MODE == 0 ? 0.f : INFINITY, nb = MODE == 0 ? 0.f : -INFINITY;
     const int bmin = (32 * c.wc) / c.HW;
@@ -249,15 +251,15 @@ __device__ __forceinline__ void board_reduce(Ctx& c, const Col& k, float& a, flo
             mb = y;
         }
     }
-    float* wp = c.wpart + c.parity * (MAXNB * NWAVE * 2);
+    float* wp = c.wpart + c.parity * (MAXNB * NW * 2);
     c.parity ^= 1;
-    if (c.lane < c.NB) *reinterpret_cast<f32x2*>(wp + (c.lane * NWAVE + c.wave) * 2) = (f32x2){ma, mb};
+    if (c.lane < c.NB) *reinterpret_cast<f32x2*>(wp + (c.lane * NW + c.wave) * 2) = (f32x2){ma, mb};
     lds_barrier();
     const int bd = k.board < MAXNB ? k.board : 0;
     float x = na, y = nb;
 #pragma unroll
-    for (int w4 = 0; w4 < NWAVE / 2; w4++) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(wp + (bd * NWAVE + 2 * w4) * 2);
+    for (int w4 = 0; w4 < NW / 2; w4++) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(wp + (bd * NW + 2 * w4) * 2);
         const float u0 = t[0], v0 = t[1], u1 = t[2], v1 = t[3];
         if (MODE == 0) {
             x += u0 + u1;
@@ -279,7 +281,7 @@ __device__ __forceinline__ void board_reduce(Ctx& c, const Col& k, float& a, flo
 }
 
 // LayerNorm statistics of this wave's NR row tiles x own column -> per-column (mean, rstd) of the board.
-template <int NR>
+template <int NR, int NW>
 __device__ __forceinline__ void ln_stats(Ctx& c, const Col& k, const f32x16 (&v)[NR], int nch, float& mean, float& rstd) {
     f32x2 s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
 #pragma unroll
@@ -292,7 +294,7 @@ __device__ __forceinline__ void ln_stats(Ctx& c, const Col& k, const f32x16 (&v)
         }
     mean = k.valid ? s2.x + s2.y : 0.f;
     rstd = k.valid ? q2.x + q2.y : 0.f;
-    board_reduce<0>(c, k, mean, rstd, 1.0f / (float)(nch * c.HW));
+    board_reduce<0, NW>(c, k, mean, rstd, 1.0f / (float)(nch * c.HW));
 }
 
 // gamma/beta of global row tile rt for this lane's (cell, channels): 4 x 16-byte loads.
@@ -358,7 +360,7 @@ __device__ __forceinline__ void img_store(char* img, int rs, int col, int rt, in
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
 // relu(LN(v)) of this wave's NR row tiles -> image rows of its own column.  gb = this LayerNorm's table.
-template <int NR>
+template <int NR, int NW>
 __device__ __forceinline__ void ln_to_image(Ctx& c, const Col& k, const u32x4* gb, const f32x16 (&v)[NR], int nch,
                                             int rs) {
     char* img = c.smem + c.L.img_off;
@@ -368,7 +370,7 @@ __device__ __forceinline__ void ln_to_image(Ctx& c, const Col& k, const u32x4* g
     if (NR > 1) gb_load(gb, c, k, c.wr * NR + 1, g[1]);
     float mean, rstd;
     STAMP(c, ST_OTHER);
-    ln_stats<NR>(c, k, v, nch, mean, rstd);
+    ln_stats<NR, NW>(c, k, v, nch, mean, rstd);
     STAMP(c, ST_STATS);
 #pragma unroll
     for (int rt = 2; rt < NR; rt++) gb_load(gb, c, k, c.wr * NR + rt, g[rt]);
@@ -385,10 +387,11 @@ __device__ __forceinline__ void ln_to_image(Ctx& c, const Col& k, const u32x4* g
 // acc[ro] += conv(image) for this wave's NROW output row tiles (of NROT in the layer).
 // Stream order of the layer's fragments: (tap, ks, ro) with natural k.  The first stage must already
 // be in flight; next_nf = first stage of whatever follows in the stream (0: nothing).
-template <int KS, int TAPS, int NROT, int NROW, int RS>
-__device__ __forceinline__ void conv_lds(Ctx& c, const Col& k, WRing& ring, f32x16 (&acc)[NROW], int next_nf) {
+template <class G, int KS, int TAPS, int NROT, int NROW, int RS>
+__device__ __forceinline__ void conv_lds(Ctx& c, const Col& k, WRing<G::NW, G::SM>& ring, f32x16 (&acc)[NROW],
+                                         int next_nf) {
     constexpr int KK = TAPS * KS;
-    constexpr int SK = stage_ksteps(KK, NROT);
+    constexpr int SK = stage_ksteps(KK, NROT, G::SM);
     const char* img = c.smem + c.L.img_off;
     const char* zrow = c.smem + c.L.zrow_off;
     const char* slot = nullptr;
@@ -432,7 +435,7 @@ __device__ __forceinline__ void zero_acc(f32x16 (&a)[NR]) {
 // BottleneckResidualBlock: x + c4(relu(LN(c3(relu(LN(c2(relu(LN(c1(relu(LN(x))))))))))))
 // On entry the first stage of c1 is in flight; on exit the first stage of whatever follows (next_nf).
 template <class G>
-__device__ __forceinline__ void bottleneck(Ctx& c, const Col& k, WRing& ring, const u32x4* gb, f32x16 (&X)[G::NRCW],
+__device__ __forceinline__ void bottleneck(Ctx& c, const Col& k, WRing<G::NW, G::SM>& ring, const u32x4* gb, f32x16 (&X)[G::NRCW],
                                            int next_nf) {
     constexpr int C = G::C, CB = G::CB;
     constexpr int RSC = C * 2 + 16, RSB = CB * 2 + 16;
@@ -445,20 +448,20 @@ __device__ __forceinline__ void bottleneck(Ctx& c, const Col& k, WRing& ring, co
     f32x16 a1[G::NRBW];
 
     // LN1 -> image -> c1 (1x1, C -> CB)
-    ln_to_image<G::NRCW>(c, k, gb1, X, C, RSC);
+    ln_to_image<G::NRCW, G::NW>(c, k, gb1, X, C, RSC);
     zero_acc<G::NRBW>(a1);
-    conv_lds<KSC, 1, G::NRB, G::NRBW, RSC>(c, k, ring, a1, first_stage_frags(9 * KSB, G::NRB));
+    conv_lds<G, KSC, 1, G::NRB, G::NRBW, RSC>(c, k, ring, a1, first_stage_frags(9 * KSB, G::NRB, G::SM));
     // LN2 -> image -> c2 (3x3), LN3 -> image -> c3 (3x3); the image is consumed before a1 is rewritten
 #pragma unroll
     for (int layer = 0; layer < 2; layer++) {
-        ln_to_image<G::NRBW>(c, k, layer == 0 ? gb2 : gb3, a1, CB, RSB);
+        ln_to_image<G::NRBW, G::NW>(c, k, layer == 0 ? gb2 : gb3, a1, CB, RSB);
         zero_acc<G::NRBW>(a1);
-        conv_lds<KSB, 9, G::NRB, G::NRBW, RSB>(
-            c, k, ring, a1, layer == 0 ? first_stage_frags(9 * KSB, G::NRB) : first_stage_frags(KSB, G::NRC));
+        conv_lds<G, KSB, 9, G::NRB, G::NRBW, RSB>(
+            c, k, ring, a1, layer == 0 ? first_stage_frags(9 * KSB, G::NRB, G::SM) : first_stage_frags(KSB, G::NRC, G::SM));
     }
     // LN4 -> image -> c4 (1x1, CB -> C) accumulated into X
-    ln_to_image<G::NRBW>(c, k, gb4, a1, CB, RSB);
-    conv_lds<KSB, 1, G::NRC, G::NRCW, RSB>(c, k, ring, X, next_nf);
+    ln_to_image<G::NRBW, G::NW>(c, k, gb4, a1, CB, RSB);
+    conv_lds<G, KSB, 1, G::NRC, G::NRCW, RSB>(c, k, ring, X, next_nf);
 }
 
 // ---- shared prologue: per-board meta data and per-lane column info -----------------------------
@@ -475,7 +478,7 @@ __device__ __forceinline__ bool setup(const NetDims& d, const NetIO& io, int NB,
         c.meta[3 * MAXNB + tid] = (ok && IN == IN_HIDDEN) ? io.action_cells[io.action[g]] : -1;
     }
     // the zero row that off-board 3x3 neighbours read
-    if (tid < ZROW_BYTES / 4) reinterpret_cast<int*>(c.smem + c.L.zrow_off)[tid] = 0;
+    if (tid < ZROW_BYTES / 16) reinterpret_cast<u32x4*>(c.smem + c.L.zrow_off)[tid] = (u32x4){0, 0, 0, 0};
     lds_barrier();
     int any = 0;
     for (int b = 0; b < NB; b++) any |= c.meta[2 * MAXNB + b];
@@ -497,7 +500,7 @@ __device__ __forceinline__ bool setup(const NetDims& d, const NetIO& io, int NB,
     return true;
 }
 
-template <int WR>
+template <class G>
 __device__ __forceinline__ void ctx_init(Ctx& c, char* smem, const LdsPlan& L, const NetDims& d, int NB) {
     const int tid = threadIdx.x;
     c.smem = smem;
@@ -507,8 +510,8 @@ __device__ __forceinline__ void ctx_init(Ctx& c, char* smem, const LdsPlan& L, c
     c.Wd = d.Wd;
     c.lane = tid & 63;
     c.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    c.wc = c.wave % (NWAVE / WR);
-    c.wr = c.wave / (NWAVE / WR);
+    c.wc = c.wave % G::WC;
+    c.wr = c.wave / G::WC;
     c.h = c.lane >> 5;
     c.r = c.lane & 31;
     c.wpart = reinterpret_cast<float*>(smem + L.stat_off);
@@ -550,24 +553,24 @@ __device__ __forceinline__ void x_store(Ctx& c, const Col& k, float* pool, int C
 
 // ---- [conv0] + bottleneck blocks b0..b1-1 + [rescale, heads] -----------------------------------
 template <class G, int IN, int OUT>
-__global__ __launch_bounds__(NT) void k_seg(NetDims d, TowerDev tw, HeadDev hd, NetIO io, LdsPlan L, int NB, int b0,
+__global__ __launch_bounds__(G::NT, G::WPE) void k_seg(NetDims d, TowerDev tw, HeadDev hd, NetIO io, LdsPlan L, int NB, int b0,
                                             int b1) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int C = G::C, CB = G::CB, NRCW = G::NRCW, WR = G::WR;
     constexpr int CIN0 = IN == IN_OBS ? 32 : C + 16;  // input channels of conv0, padded to 16
     constexpr int KS0 = CIN0 / 16;
     constexpr int RS0 = CIN0 * 2 + 16;
-    constexpr int FS_C1 = first_stage_frags(C / 16, G::NRB);
+    constexpr int FS_C1 = first_stage_frags(C / 16, G::NRB, G::SM);
     const int tid = threadIdx.x;
     Ctx c;
-    ctx_init<WR>(c, smem, L, d, NB);
+    ctx_init<G>(c, smem, L, d, NB);
     Col k;
     if (!setup<IN>(d, io, NB, c, k)) return;
     const int HW = d.HW, A = d.A;
     const int g0 = blockIdx.x * NB;
     char* img = smem + L.img_off;
 
-    WRing ring;
+    WRing<G::NW, G::SM> ring;
     f32x16 X[NRCW];
     if (IN == IN_X) {
         ring.init(tw.stream + (long long)tw.foff[b0] * 64, smem + L.ring_off, c.wave, c.lane);
@@ -576,7 +579,7 @@ __global__ __launch_bounds__(NT) void k_seg(NetDims d, TowerDev tw, HeadDev hd, 
         STAMP(c, ST_XLOAD);
     } else {
         ring.init(tw.stream, smem + L.ring_off, c.wave, c.lane);
-        ring.issue(first_stage_frags(9 * KS0, G::NRC));
+        ring.issue(first_stage_frags(9 * KS0, G::NRC, G::SM));
         // ---------------- input image + conv0 ----------------
         if (IN == IN_OBS) {
             zero_acc<NRCW>(X);
@@ -612,7 +615,7 @@ __global__ __launch_bounds__(NT) void k_seg(NetDims d, TowerDev tw, HeadDev hd, 
                 *reinterpret_cast<bf16x8*>(img + k.col * RS0 + (C + 8 * c.h) * 2) = pack8(&y[0]);
             }
         }
-        conv_lds<KS0, 9, G::NRC, NRCW, RS0>(c, k, ring, X, b0 < b1 ? FS_C1 : 0);
+        conv_lds<G, KS0, 9, G::NRC, NRCW, RS0>(c, k, ring, X, b0 < b1 ? FS_C1 : 0);
     }
 
     {
@@ -643,7 +646,7 @@ __global__ __launch_bounds__(NT) void k_seg(NetDims d, TowerDev tw, HeadDev hd, 
             mn = INFINITY;
             mx = -INFINITY;
         }
-        board_reduce<1>(c, k, mn, mx, 0.f);
+        board_reduce<1, G::NW>(c, k, mn, mx, 0.f);
         const float dd = fmaxf(mx - mn, 1e-5f);
 #pragma unroll
         for (int rt = 0; rt < NRCW; rt++)
@@ -819,14 +822,14 @@ size_t heads_lds_bytes(const NetDims& d) {
 // LDS: [image, C channels][region 2]; region 2 is the weight ring while c1 and c2 run and the
 // transposed image TB[channel][board*KP + cell] while the broadcast linear runs.
 template <class G>
-__global__ __launch_bounds__(NT) void k_bcast(NetDims d, TowerDev tw, NetIO io, LdsPlan L, int NB, int blk) {
+__global__ __launch_bounds__(G::NT, G::WPE) void k_bcast(NetDims d, TowerDev tw, NetIO io, LdsPlan L, int NB, int blk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int C = G::C, NRC = G::NRC, NRCW = G::NRCW, WR = G::WR;
     constexpr int RS = C * 2 + 16;
     constexpr int KSC = C / 16;
-    constexpr int FS = first_stage_frags(KSC, NRC);
+    constexpr int FS = first_stage_frags(KSC, NRC, G::SM);
     Ctx c;
-    ctx_init<WR>(c, smem, L, d, NB);
+    ctx_init<G>(c, smem, L, d, NB);
     Col k;
     if (!setup<IN_X>(d, io, NB, c, k)) return;
     const long long e = c.HW + 1;
@@ -838,7 +841,7 @@ __global__ __launch_bounds__(NT) void k_bcast(NetDims d, TowerDev tw, NetIO io, 
     const int KP = L.kp, QT = L.qt, TBS = L.tbs;
     char* tb = smem + L.tb_off;
     char* img = smem + L.img_off;
-    WRing ring;
+    WRing<G::NW, G::SM> ring;
     ring.init(tw.stream + (long long)tw.foff[blk] * 64, smem + L.ring_off, c.wave, c.lane);
     ring.issue(FS);
     f32x16 X[NRCW];
@@ -846,16 +849,16 @@ __global__ __launch_bounds__(NT) void k_bcast(NetDims d, TowerDev tw, NetIO io, 
     {
         // LN1 -> image -> c1 (1x1, C -> C); this wave's share of the output rows stays in registers
         f32x16 a[NRCW];
-        ln_to_image<NRCW>(c, k, gb1, X, C, RS);
+        ln_to_image<NRCW, G::NW>(c, k, gb1, X, C, RS);
         zero_acc<NRCW>(a);
-        conv_lds<KSC, 1, NRC, NRCW, RS>(c, k, ring, a, 0);
+        conv_lds<G, KSC, 1, NRC, NRCW, RS>(c, k, ring, a, 0);
         STAMP(c, ST_OTHER);
         // LN2 + ReLU -> bf16 -> transposed image TB (the statistics barrier proves that every wave has
         // finished c1, so the ring under TB is dead)
         u32x4 g[4];
         float mean, rstd;
-        ln_stats<NRCW>(c, k, a, C, mean, rstd);
-        for (int i = threadIdx.x; i < C * NB * (KP - c.HW); i += NT) {  // zero the K padding of every board
+        ln_stats<NRCW, G::NW>(c, k, a, C, mean, rstd);
+        for (int i = threadIdx.x; i < C * NB * (KP - c.HW); i += G::NT) {  // zero the K padding of every board
             const int padw = KP - c.HW;
             const int ch = i / (NB * padw), rem = i - ch * (NB * padw);
             const int bd = rem / padw, pp = rem - bd * padw;
@@ -880,11 +883,11 @@ __global__ __launch_bounds__(NT) void k_bcast(NetDims d, TowerDev tw, NetIO io, 
     // BroadcastBlock: out[ch][q] = sum_p in[ch][p] * Wb[q][p] + b[q], per board.  Work items (board, row
     // tile, q tile) are dealt round-robin to the waves.  Pass 0 accumulates the LN3 statistics, pass 1
     // recomputes and writes relu(LN3(.)) to the image.
-    float* ipart = c.wpart + 2 * MAXNB * NWAVE * 2;   // [items][2]
+    float* ipart = c.wpart + 2 * MAXNB * G::NW * 2;   // [items][2]
     float* bstat = ipart + 2 * 256;                   // [MAXNB][2]
     const int nitems = NB * NRC * QT;
     for (int pass = 0; pass < 2; pass++) {
-        for (int it = c.wave; it < nitems; it += NWAVE) {
+        for (int it = c.wave; it < nitems; it += G::NW) {
             const int bd = it / (NRC * QT), rem = it - bd * (NRC * QT);
             const int rtw = rem / QT, qt = rem - rtw * QT;
             f32x16 acc;
@@ -960,7 +963,7 @@ __global__ __launch_bounds__(NT) void k_bcast(NetDims d, TowerDev tw, NetIO io, 
     STAMP(c, ST_BCAST);
     // c2: 1x1 conv C -> C on the image (own columns), accumulated into X
     ring.issue(FS);
-    conv_lds<KSC, 1, NRC, NRCW, RS>(c, k, ring, X, 0);
+    conv_lds<G, KSC, 1, NRC, NRCW, RS>(c, k, ring, X, 0);
     x_store<NRCW>(c, k, io.pool, C, X);
     STAMP(c, ST_XSTORE);
     STAMP_PRINT(c, "bcast");
@@ -1027,7 +1030,7 @@ struct TowerHost {
 
 struct MfmaNet {
     NetDims d{};
-    int NB = 0, WR = 1, COLS = 256;
+    int geom = 0, NB = 0, WR = 1, NW = 8, SM = 32, COLS = 256;
     LdsPlan Lseg{}, Lbc{};
     void* bufs[16] = {nullptr};
     int nbufs = 0;
@@ -1045,41 +1048,41 @@ bool shape_supported(const NetDims& d) {
 
 int align16(int x) { return (x + 15) / 16 * 16; }
 
-void plan_tail(LdsPlan& L, int end) {
+void plan_tail(LdsPlan& L, int end, int NW) {
     end = align16(end);
     L.zrow_off = end;
     end += ZROW_BYTES;
     L.stat_off = end;
-    end += (2 * MAXNB * NWAVE * 2 + 2 * 256 + 2 * MAXNB) * 4;  // wpart x2, ipart, bstat
+    end += (2 * MAXNB * NW * 2 + 2 * 256 + 2 * MAXNB) * 4;  // wpart x2, ipart, bstat
     L.meta_off = end;
     end += 4 * MAXNB * 4;
     L.total = align16(end);
 }
 
 // k_seg: [ring][image]
-LdsPlan make_plan_seg(const NetDims& d, int COLS, int WR) {
+LdsPlan make_plan_seg(const NetDims& d, int COLS, int NW, int SM) {
     LdsPlan L{};
     const int rs0 = (d.C + 16) * 2 + 16;
     // the ring comes first: LDS-DMA destinations stay below 64 KiB
     L.ring_off = 0;
-    L.img_off = 2 * SMAX * 1024;
+    L.img_off = 2 * SM * 1024;
     int end = L.img_off + align16(COLS * rs0);
     L.head_off = 0;
-    plan_tail(L, end);
+    plan_tail(L, end, NW);
     return L;
 }
 // k_bcast: [region 2 = ring / TB][image, C channels]
-LdsPlan make_plan_bcast(const NetDims& d, int COLS, int NB) {
+LdsPlan make_plan_bcast(const NetDims& d, int COLS, int NB, int NW, int SM) {
     LdsPlan L{};
     const int rsc = d.C * 2 + 16;
     L.kp = (d.HW + 15) / 16 * 16;
     L.qt = (d.HW + 31) / 32;
     L.tbs = (NB * L.kp + 8) * 2;
-    const int ring = 2 * SMAX * 1024, tbb = align16(d.C * L.tbs);
+    const int ring = 2 * SM * 1024, tbb = align16(d.C * L.tbs);
     L.ring_off = 0;
     L.tb_off = 0;
     L.img_off = ring > tbb ? ring : tbb;
-    plan_tail(L, L.img_off + align16(COLS * rsc));
+    plan_tail(L, L.img_off + align16(COLS * rsc), NW);
     return L;
 }
 
@@ -1112,12 +1115,34 @@ MfmaNet* mfma_create(const NetDims& d, int /*max_batch*/, std::string* err) {
     }
     MfmaNet* n = new MfmaNet();
     n->d = d;
-    n->WR = d.C == 256 ? 2 : 1;
-    n->COLS = 32 * (NWAVE / n->WR);
+    // Workgroup geometry (see Geo): numChannels 256 -> 2x4 waves on 128 columns; numChannels 128 -> 1x8 waves on 256
+    // columns (measured best on Go 9x9: 1.31 ms per recurrentInference of 4096 boards against 1.55 / 1.58 / 1.42 ms
+    // for the 2x3, 2x4 and 2x8 grids, which trade column packing for a second workgroup per CU).  MZ_GEOM picks
+    // one of the other grids (diagnostics).
+    struct GeomDesc { int WR, NW, SM; };
+    static const GeomDesc kGeom[5] = {{1, 8, 32}, {2, 6, 16}, {2, 8, 16}, {2, 8, 32}, {2, 16, 32}};
+    if (d.C == 256) {
+        n->geom = 3;
+    } else {
+        n->geom = 0;
+        if (const char* e = std::getenv("MZ_GEOM")) {
+            const int g = std::atoi(e);
+            if ((g >= 0 && g <= 2) || g == 4) n->geom = g;
+        }
+    }
+    n->WR = kGeom[n->geom].WR;
+    n->NW = kGeom[n->geom].NW;
+    n->SM = kGeom[n->geom].SM;
+    n->COLS = 32 * (n->NW / n->WR);
     n->NB = n->COLS / d.HW;
     if (n->NB > MAXNB) n->NB = MAXNB;
-    n->Lseg = make_plan_seg(d, n->COLS, n->WR);
-    n->Lbc = make_plan_bcast(d, n->COLS, n->NB);
+    if (n->NB < 1) {
+        if (err) *err = "board does not fit the workgroup tile";
+        delete n;
+        return nullptr;
+    }
+    n->Lseg = make_plan_seg(d, n->COLS, n->NW, n->SM);
+    n->Lbc = make_plan_bcast(d, n->COLS, n->NB, n->NW, n->SM);
     const int bc_items = n->NB * (d.C / 32) * n->Lbc.qt;
     const bool has_bcast = d.bcast_every_n > 0 && d.R >= d.bcast_every_n;
     if (n->Lseg.total > 160 * 1024 || (has_bcast && (n->Lbc.total > 160 * 1024 || bc_items > 256))) {
@@ -1258,7 +1283,7 @@ void launch_seg(MfmaNet* n, hipStream_t st, int grid, const NetDims& d, const To
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_seg<G, IN, OUT>), dim3(grid), dim3(NT), n->Lseg.total, st, d, tw, n->hd, io, n->Lseg, n->NB,
+    hipLaunchKernelGGL((k_seg<G, IN, OUT>), dim3(grid), dim3(G::NT), n->Lseg.total, st, d, tw, n->hd, io, n->Lseg, n->NB,
                        b0, b1);
 }
 
@@ -1300,7 +1325,7 @@ int forward_t(MfmaNet* n, hipStream_t st, bool initial, const NetDims& d, const 
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             bc_attr = true;
         }
-        hipLaunchKernelGGL((k_bcast<G>), dim3(grid), dim3(NT), n->Lbc.total, st, d, tw, io, n->Lbc, n->NB, e);
+        hipLaunchKernelGGL((k_bcast<G>), dim3(grid), dim3(G::NT), n->Lbc.total, st, d, tw, io, n->Lbc, n->NB, e);
         b = e + 1;
     }
     return 0;
@@ -1313,8 +1338,13 @@ int mfma_forward(MfmaNet* n, hipStream_t st, bool initial, const NetDims& d, con
         if (err) *err = "mfma weights not packed";
         return -1;
     }
-    if (n->WR == 1) return forward_t<Geo<128, 64, 1>>(n, st, initial, d, io);
-    return forward_t<Geo<256, 128, 2>>(n, st, initial, d, io);
+    switch (n->geom) {
+        case 0: return forward_t<Geo<128, 64, 1, 8, 32, 2>>(n, st, initial, d, io);
+        case 1: return forward_t<Geo<128, 64, 2, 6, 16, 3>>(n, st, initial, d, io);
+        case 2: return forward_t<Geo<128, 64, 2, 8, 16, 4>>(n, st, initial, d, io);
+        case 4: return forward_t<Geo<128, 64, 2, 16, 32, 4>>(n, st, initial, d, io);
+        default: return forward_t<Geo<256, 128, 2, 8, 32, 2>>(n, st, initial, d, io);
+    }
 }
 
 }  // namespace mz
