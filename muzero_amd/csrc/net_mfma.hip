@@ -530,13 +530,15 @@ __device__ __forceinline__ void x_load(Ctx& c, const Col& k, const float* pool, 
     // a per-load branch would serialise dependent round trips
     const int bd = k.valid ? k.board : 0;
     const float* src = pool + (long long)c.meta[which * MAXNB + bd] * C * c.HW + k.p;
+    int hw = c.HW;
+    asm volatile("" : "+s"(hw));   // opaque per call: keeps the compiler from holding (and spilling) 64 row offsets
     const bool keep = k.live;
 #pragma unroll
     for (int rt = 0; rt < NR; rt++)
 #pragma unroll
         for (int i = 0; i < 16; i++) {
             const int ch = 32 * (c.wr * NR + rt) + (i & 3) + 8 * (i >> 2) + 4 * c.h;
-            const float v = src[ch * c.HW];
+            const float v = src[ch * hw];
             X[rt][i] = keep ? v : 0.f;  // select, not multiply: dead slots may hold NaN bit patterns
         }
 }
@@ -544,11 +546,12 @@ template <int NR>
 __device__ __forceinline__ void x_store(Ctx& c, const Col& k, float* pool, int C, const f32x16 (&X)[NR]) {
     if (!k.live) return;
     float* dst = pool + (long long)c.meta[MAXNB + k.board] * C * c.HW + k.p;
+    int hw = c.HW;
+    asm volatile("" : "+s"(hw));
 #pragma unroll
     for (int rt = 0; rt < NR; rt++)
 #pragma unroll
-        for (int i = 0; i < 16; i++)
-            dst[(long long)(32 * (c.wr * NR + rt) + (i & 3) + 8 * (i >> 2) + 4 * c.h) * c.HW] = X[rt][i];
+        for (int i = 0; i < 16; i++) dst[(32 * (c.wr * NR + rt) + (i & 3) + 8 * (i >> 2) + 4 * c.h) * hw] = X[rt][i];
 }
 
 // ---- [conv0] + bottleneck blocks b0..b1-1 + [rescale, heads] -----------------------------------
@@ -821,10 +824,12 @@ size_t heads_lds_bytes(const NetDims& d) {
 // ---- BroadcastResidualBlock: x + c2(relu(LN(bcast(relu(LN(c1(relu(LN(x))))))))) ------------------
 // LDS: [image, C channels][region 2]; region 2 is the weight ring while c1 and c2 run and the
 // transposed image TB[channel][board*KP + cell] while the broadcast linear runs.
-template <class G>
+// KSB = k-steps of the broadcast linear (cells padded to 16*KSB); its weight fragments stay in registers.
+template <class G, int KSB>
 __global__ __launch_bounds__(G::NT, G::WPE) void k_bcast(NetDims d, TowerDev tw, NetIO io, LdsPlan L, int NB, int blk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int C = G::C, NRC = G::NRC, NRCW = G::NRCW, WR = G::WR;
+    constexpr int C = G::C, NRC = G::NRC, NRCW = G::NRCW;
+    constexpr int QT = (KSB + 1) / 2, KP = 16 * KSB;
     constexpr int RS = C * 2 + 16;
     constexpr int KSC = C / 16;
     constexpr int FS = first_stage_frags(KSC, NRC, G::SM);
@@ -838,7 +843,7 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_bcast(NetDims d, TowerDev tw,
     const u32x4* gb3 = gb2 + NRC * 8 * e;
     const u32x4* wbf = tw.wbf + tw.wboff[blk];
     const float* bb = tw.bb + tw.bboff[blk];
-    const int KP = L.kp, QT = L.qt, TBS = L.tbs;
+    const int TBS = L.tbs;
     char* tb = smem + L.tb_off;
     char* img = smem + L.img_off;
     WRing<G::NW, G::SM> ring;
@@ -879,68 +884,87 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_bcast(NetDims d, TowerDev tw,
             }
         }
     }
+    // broadcast-linear B fragments and bias (requested here, once the c1 tiles are dead): lane (q = 32qt + r, h) holds Wb[q][16ks + 8h + j]
+    u32x4 wreg[KSB][QT];
+    float bias[QT];
+#pragma unroll
+    for (int ks = 0; ks < KSB; ks++)
+#pragma unroll
+        for (int qt = 0; qt < QT; qt++) wreg[ks][qt] = wbf[(ks * QT + qt) * 64 + c.lane];
+#pragma unroll
+    for (int qt = 0; qt < QT; qt++) bias[qt] = bb[32 * qt + c.r];
+    __builtin_amdgcn_sched_barrier(0);
     lds_barrier();
-    // BroadcastBlock: out[ch][q] = sum_p in[ch][p] * Wb[q][p] + b[q], per board.  Work items (board, row
-    // tile, q tile) are dealt round-robin to the waves.  Pass 0 accumulates the LN3 statistics, pass 1
-    // recomputes and writes relu(LN3(.)) to the image.
+    STAMP(c, ST_HCONV);   // (diagnostic slots reused: hconv = LN2 + transpose, hln = pass 0, hfc = statistics)
+    // BroadcastBlock: out[ch][q] = sum_p in[ch][p] * Wb[q][p] + b[q], per board.  Work items (board, row tile)
+    // are dealt round-robin to the waves; an item covers all QT q tiles, one after the other.
+    // Pass 0 accumulates the LN3 statistics, pass 1 recomputes (36 MFMAs, cheaper than holding the tiles) and
+    // writes relu(LN3(.)) to the image; its gamma/beta loads are requested before the recompute.
     float* ipart = c.wpart + 2 * MAXNB * G::NW * 2;   // [items][2]
     float* bstat = ipart + 2 * 256;                   // [MAXNB][2]
-    const int nitems = NB * NRC * QT;
+    const int nitems = NB * NRC;
     for (int pass = 0; pass < 2; pass++) {
         for (int it = c.wave; it < nitems; it += G::NW) {
-            const int bd = it / (NRC * QT), rem = it - bd * (NRC * QT);
-            const int rtw = rem / QT, qt = rem - rtw * QT;
-            f32x16 acc;
+            const int bd = it / NRC, rtw = it - bd * NRC;
+            const char* arow = tb + (32 * rtw + c.r) * TBS + (bd * KP + 8 * c.h) * 2;
+            float ps = 0.f, pq = 0.f;
 #pragma unroll
-            for (int i = 0; i < 16; i++) acc[i] = 0.f;
-            for (int ks = 0; ks < KP / 16; ks++) {
-                bf16x8 a = __builtin_bit_cast(
-                    bf16x8, *reinterpret_cast<const u32x4*>(tb + (32 * rtw + c.r) * TBS + (bd * KP + 16 * ks + 8 * c.h) * 2));
-                bf16x8 b = __builtin_bit_cast(bf16x8, wbf[(ks * QT + qt) * 64 + c.lane]);
-                acc = MFMA(a, b, acc);
-            }
-            const int q = 32 * qt + c.r;
-            const bool qv = q < c.HW;
-            const float bias = bb[q];
-            if (pass == 0) {
-                float ps = 0.f, pq = 0.f;
-                if (qv) {
+            for (int qt = 0; qt < QT; qt++) {
+                const int q = 32 * qt + c.r;
+                const bool qv = q < c.HW;
+                u32x4 g[4];
+                if (pass == 1) {
+                    const unsigned stride = (unsigned)(c.HW + 1) * 32u;
+                    const unsigned off = (unsigned)(c.h * (c.HW + 1) + (qv ? q : c.HW)) * 16u + (unsigned)(rtw * 4) * stride;
 #pragma unroll
-                    for (int i = 0; i < 16; i++) {
-                        float x = acc[i] + bias;
-                        ps += x;
-                        pq = fmaf(x, x, pq);
-                    }
+                    for (int qd = 0; qd < 4; qd++)
+                        g[qd] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(gb3) + off + qd * stride);
+                    __builtin_amdgcn_sched_barrier(0x38F);
                 }
+                f32x16 acc;
+#pragma unroll
+                for (int i = 0; i < 16; i++) acc[i] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KSB; ks++) {
+                    const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(arow + 32 * ks));
+                    acc = MFMA(a, __builtin_bit_cast(bf16x8, wreg[ks][qt]), acc);
+                }
+                if (pass == 0) {
+                    if (qv) {
+#pragma unroll
+                        for (int i = 0; i < 16; i++) {
+                            const float x = acc[i] + bias[qt];
+                            ps += x;
+                            pq = fmaf(x, x, pq);
+                        }
+                    }
+                } else if (qv) {
+                    const float bmean = bstat[2 * bd], brstd = bstat[2 * bd + 1];
+#pragma unroll
+                    for (int i = 0; i < 16; i++) acc[i] += bias[qt];
+                    float y[16];
+                    ln_apply(acc, bmean, brstd, g, y);
+                    img_store(img, RS, bd * c.HW + q, rtw, c.h, y);
+                }
+            }
+            if (pass == 0) {
                 ps = wave_red<0>(ps);
                 pq = wave_red<0>(pq);
                 if (c.lane == 0) {
                     ipart[2 * it] = ps;
                     ipart[2 * it + 1] = pq;
                 }
-            } else if (qv) {
-                const float bmean = bstat[2 * bd], brstd = bstat[2 * bd + 1];
-                u32x4 g[4];
-                const unsigned stride = (unsigned)(c.HW + 1) * 32u;
-                const unsigned off = (unsigned)(c.h * (c.HW + 1) + q) * 16u + (unsigned)(rtw * 4) * stride;
-#pragma unroll
-                for (int qd = 0; qd < 4; qd++)
-                    g[qd] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(gb3) + off + qd * stride);
-#pragma unroll
-                for (int i = 0; i < 16; i++) acc[i] += bias;
-                float y[16];
-                ln_apply(acc, bmean, brstd, g, y);
-                img_store(img, RS, bd * c.HW + q, rtw, c.h, y);
             }
         }
         if (pass == 0) {
+            STAMP(c, ST_HLN);
             lds_barrier();
             if ((int)threadIdx.x < NB) {
                 const int bd = threadIdx.x;
                 float s = 0.f, q = 0.f;
-                for (int j = 0; j < NRC * QT; j++) {
-                    s += ipart[2 * (bd * NRC * QT + j)];
-                    q += ipart[2 * (bd * NRC * QT + j) + 1];
+                for (int j = 0; j < NRC; j++) {
+                    s += ipart[2 * (bd * NRC + j)];
+                    q += ipart[2 * (bd * NRC + j) + 1];
                 }
                 const float ninv = 1.0f / (float)(C * c.HW);
                 const float mean = s * ninv;
@@ -949,6 +973,7 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_bcast(NetDims d, TowerDev tw,
                 bstat[2 * bd + 1] = 1.0f / sqrtf(var + 1e-5f);
             }
             lds_barrier();
+            STAMP(c, ST_HFC);
         }
     }
     // padded columns of the image (beyond NB*HW) feed only padded outputs, but must be finite
@@ -961,8 +986,9 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_bcast(NetDims d, TowerDev tw,
     }
     lds_barrier();   // image complete, TB dead: region 2 is the ring again
     STAMP(c, ST_BCAST);
-    // c2: 1x1 conv C -> C on the image (own columns), accumulated into X
+    // c2: 1x1 conv C -> C on the image (own columns), accumulated into X (re-read: it was not held in registers)
     ring.issue(FS);
+    x_load<NRCW>(c, k, io.pool, 1, C, X);
     conv_lds<G, KSC, 1, NRC, NRCW, RS>(c, k, ring, X, 0);
     x_store<NRCW>(c, k, io.pool, C, X);
     STAMP(c, ST_XSTORE);
@@ -1127,7 +1153,7 @@ MfmaNet* mfma_create(const NetDims& d, int /*max_batch*/, std::string* err) {
         n->geom = 0;
         if (const char* e = std::getenv("MZ_GEOM")) {
             const int g = std::atoi(e);
-            if ((g >= 0 && g <= 2) || g == 4) n->geom = g;
+            if (g == 0) n->geom = g;   // the 2x3 / 2x4 / 2x8 grids (1, 2, 4) are not instantiated in this build
         }
     }
     n->WR = kGeom[n->geom].WR;
@@ -1287,6 +1313,17 @@ void launch_seg(MfmaNet* n, hipStream_t st, int grid, const NetDims& d, const To
                        b0, b1);
 }
 
+template <class G, int KSB>
+void launch_bcast(MfmaNet* n, hipStream_t st, int grid, const NetDims& d, const TowerDev& tw, const NetIO& io, int blk) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bcast<G, KSB>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_bcast<G, KSB>), dim3(grid), dim3(G::NT), n->Lbc.total, st, d, tw, io, n->Lbc, n->NB, blk);
+}
+
 template <class G>
 int forward_t(MfmaNet* n, hipStream_t st, bool initial, const NetDims& d, const NetIO& io) {
     const int grid = (io.B + n->NB - 1) / n->NB;
@@ -1319,13 +1356,14 @@ int forward_t(MfmaNet* n, hipStream_t st, bool initial, const NetDims& d, const 
         if (last) hipLaunchKernelGGL(k_heads, dim3(io.B), dim3(HT), heads_lds_bytes(d), st, d, n->hd, io);
         first = false;
         if (last || (dbg_stop >= 0 && dbg_stop == e)) break;
-        static bool bc_attr = false;
-        if (!bc_attr) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bcast<G>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            bc_attr = true;
+        switch (n->Lbc.kp / 16) {
+            case 1: launch_bcast<G, 1>(n, st, grid, d, tw, io, e); break;
+            case 2: launch_bcast<G, 2>(n, st, grid, d, tw, io, e); break;
+            case 3: launch_bcast<G, 3>(n, st, grid, d, tw, io, e); break;
+            case 4: launch_bcast<G, 4>(n, st, grid, d, tw, io, e); break;
+            case 5: launch_bcast<G, 5>(n, st, grid, d, tw, io, e); break;
+            default: launch_bcast<G, 6>(n, st, grid, d, tw, io, e); break;
         }
-        hipLaunchKernelGGL((k_bcast<G>), dim3(grid), dim3(G::NT), n->Lbc.total, st, d, tw, io, n->Lbc, n->NB, e);
         b = e + 1;
     }
     return 0;
@@ -1340,9 +1378,6 @@ int mfma_forward(MfmaNet* n, hipStream_t st, bool initial, const NetDims& d, con
     }
     switch (n->geom) {
         case 0: return forward_t<Geo<128, 64, 1, 8, 32, 2>>(n, st, initial, d, io);
-        case 1: return forward_t<Geo<128, 64, 2, 6, 16, 3>>(n, st, initial, d, io);
-        case 2: return forward_t<Geo<128, 64, 2, 8, 16, 4>>(n, st, initial, d, io);
-        case 4: return forward_t<Geo<128, 64, 2, 16, 32, 4>>(n, st, initial, d, io);
         default: return forward_t<Geo<256, 128, 2, 8, 32, 2>>(n, st, initial, d, io);
     }
 }
