@@ -18,9 +18,11 @@
 //     (a zero row for off-board cells) - the implicit GEMM, never materialised.
 //   * Weights are packed on the host into 1 KiB MFMA A-fragments in exact execution order, one linear
 //     stream per tower.  The workgroup streams them global -> LDS with global_load_lds_dwordx4 (no
-//     registers) into a two-slot ring; a slot holds one stage (<= 32 fragments) that all 8 waves read
-//     with ds_read_b128.  One barrier per stage publishes the slot that was loaded during the previous
-//     stage and frees the other one for the next prefetch.
+//     registers) into a three-slot ring, two stages ahead; a slot holds one stage (<= 24 fragments) that
+//     all 8 waves read with ds_read_b128.  One barrier per stage publishes the slot that was requested
+//     two stages ago and frees the one just computed for the next prefetch.
+//   * The prediction heads (tiny fp32 latency chains) run in their own kernel, one small workgroup per
+//     sample at high occupancy, off the hidden state the tower has just written.
 //   * LayerNorm over (C,H,W) of a sample = per-lane partial sums -> masked DPP butterfly per board ->
 //     per-wave partials in LDS -> one barrier -> per-board mean / rstd.  ReLU, residual add, min-max
 //     rescale, softmax and the value scaling are fused too.
@@ -120,10 +122,17 @@ constexpr int stage_ksteps(int KK, int NROT, int SM) {
     const int nst = (KK + skmax - 1) / skmax;
     return (KK + nst - 1) / nst;
 }
-constexpr int first_stage_frags(int KK, int NROT, int SM) {
+constexpr int num_stages(int KK, int NROT, int SM) {
     const int sk = stage_ksteps(KK, NROT, SM);
-    return (sk < KK ? sk : KK) * NROT;
+    return (KK + sk - 1) / sk;
 }
+// fragments of stage j of that conv (0 past its last stage)
+constexpr int stage_frags(int KK, int NROT, int SM, int j) {
+    const int sk = stage_ksteps(KK, NROT, SM);
+    const int rem = KK - j * sk;
+    return rem <= 0 ? 0 : (rem < sk ? rem : sk) * NROT;
+}
+constexpr int NSLOT = 3;   // ring slots: the stage being computed + two in flight
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -163,26 +172,27 @@ struct Ctx {
 #endif
 };
 
-// Two-slot LDS ring over the linear A-fragment stream, filled by LDS-DMA.  Protocol (all waves):
-//   issue(S0);  acquire() -> issue(S1) -> compute S0;  acquire() -> issue(S2) -> compute S1; ...
-// acquire() waits for this wave's own DMA of the stage, then the workgroup barrier makes every wave's
-// part visible and proves that all waves have left the slot the next issue() overwrites.
+// Three-slot LDS ring over the linear A-fragment stream, filled by LDS-DMA two stages ahead.  Protocol (all waves):
+//   issue(S0); issue(S1);  acquire() -> issue(S2) -> compute S0;  acquire() -> issue(S3) -> compute S1; ...
+// acquire() waits for this wave's own DMA (vmcnt(0): the stage due now was requested two stages ago, the next
+// one a whole stage ago), then the workgroup barrier makes every wave's part visible and proves that all waves
+// have left the slot the next issue() overwrites (the one computed before the barrier).
 template <int NW, int SM>
 struct WRing {
     const char* gptr;  // next fragment to load (wave-uniform)
     char* lds;         // ring base
-    int ld_par, rd_par, wave;
+    int ld_idx, rd_idx, wave;
     unsigned lane16;
     __device__ __forceinline__ void init(const u32x4* stream, char* ring, int wave_, int lane) {
         gptr = reinterpret_cast<const char*>(stream);
         lds = ring;
-        ld_par = rd_par = 0;
+        ld_idx = rd_idx = 0;
         wave = wave_;
         lane16 = (unsigned)lane * 16u;
     }
     __device__ __forceinline__ void issue(int nf) {
-        if (nf == 0) return;   // nothing follows: the slot parity stays with the next real issue()
-        char* dst = lds + ld_par * (SM * 1024);
+        if (nf == 0) return;   // nothing follows: the slot stays with the next real issue()
+        char* dst = lds + ld_idx * (SM * 1024);
 #pragma unroll
         for (int i = 0; i < (SM + NW - 1) / NW; i++) {
             const int f = wave + NW * i;
@@ -192,12 +202,12 @@ struct WRing {
                     (__attribute__((address_space(3))) void*)(dst + f * 1024), 16, 0, 0);
         }
         gptr += (size_t)nf * 1024;
-        ld_par ^= 1;
+        ld_idx = ld_idx == NSLOT - 1 ? 0 : ld_idx + 1;
     }
     __device__ __forceinline__ const char* acquire() {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        const char* p = lds + rd_par * (SM * 1024);
-        rd_par ^= 1;
+        const char* p = lds + rd_idx * (SM * 1024);
+        rd_idx = rd_idx == NSLOT - 1 ? 0 : rd_idx + 1;
         return p;
     }
 };
@@ -385,13 +395,14 @@ __device__ __forceinline__ void ln_to_image(Ctx& c, const Col& k, const u32x4* g
 }
 
 // acc[ro] += conv(image) for this wave's NROW output row tiles (of NROT in the layer).
-// Stream order of the layer's fragments: (tap, ks, ro) with natural k.  The first stage must already
-// be in flight; next_nf = first stage of whatever follows in the stream (0: nothing).
+// Stream order of the layer's fragments: (tap, ks, ro) with natural k.  The first two stages of the stream from
+// here on must already be in flight; after1 / after2 = the two stages that follow this conv's last (0: nothing).
 template <class G, int KS, int TAPS, int NROT, int NROW, int RS>
 __device__ __forceinline__ void conv_lds(Ctx& c, const Col& k, WRing<G::NW, G::SM>& ring, f32x16 (&acc)[NROW],
-                                         int next_nf) {
+                                         int after1, int after2) {
     constexpr int KK = TAPS * KS;
     constexpr int SK = stage_ksteps(KK, NROT, G::SM);
+    constexpr int NST = num_stages(KK, NROT, G::SM);
     const char* img = c.smem + c.L.img_off;
     const char* zrow = c.smem + c.L.zrow_off;
     const char* slot = nullptr;
@@ -401,9 +412,8 @@ __device__ __forceinline__ void conv_lds(Ctx& c, const Col& k, WRing<G::NW, G::S
             STAMP(c, kk == 0 ? ST_OTHER : ST_MMA);
             slot = ring.acquire() + (c.wr * NROW) * 1024 + c.lane * 16;
             STAMP(c, ST_ACQ);
-            const int rem = KK - (kk + SK);
-            const int nfn = rem > 0 ? (rem < SK ? rem : SK) * NROT : next_nf;
-            ring.issue(nfn);
+            const int j = kk / SK + 2;   // the stage requested now
+            ring.issue(j < NST ? stage_frags(KK, NROT, G::SM, j) : (j == NST ? after1 : after2));
         }
         const int t = kk / KS, ks = kk % KS;
         const char* row;
@@ -433,11 +443,25 @@ __device__ __forceinline__ void zero_acc(f32x16 (&a)[NR]) {
 }
 
 // BottleneckResidualBlock: x + c4(relu(LN(c3(relu(LN(c2(relu(LN(c1(relu(LN(x))))))))))))
-// On entry the first stage of c1 is in flight; on exit the first stage of whatever follows (next_nf).
+// Stage sizes of a block's four convs, and the two stages that open a block.
+template <class G>
+struct BlockStages {
+    static constexpr int KSC = G::C / 16, KSB = G::CB / 16, SM = G::SM;
+    static constexpr int c1(int j) { return stage_frags(KSC, G::NRB, SM, j); }
+    static constexpr int c2(int j) { return stage_frags(9 * KSB, G::NRB, SM, j); }
+    static constexpr int c4(int j) { return stage_frags(KSB, G::NRC, SM, j); }
+    static constexpr int n1 = num_stages(KSC, G::NRB, SM), n4 = num_stages(KSB, G::NRC, SM);
+    static_assert(num_stages(9 * KSB, G::NRB, SM) >= 2, "3x3 convs span at least two stages");
+    static constexpr int open0 = c1(0), open1 = n1 > 1 ? c1(1) : c2(0);
+};
+
+// On entry the first two stages of the block are in flight; on exit those of the next block (if has_next).
 template <class G>
 __device__ __forceinline__ void bottleneck(Ctx& c, const Col& k, WRing<G::NW, G::SM>& ring, const u32x4* gb, f32x16 (&X)[G::NRCW],
-                                           int next_nf) {
+                                           bool has_next) {
     constexpr int C = G::C, CB = G::CB;
+    using BS = BlockStages<G>;
+    const int nx0 = has_next ? BS::open0 : 0, nx1 = has_next ? BS::open1 : 0;
     constexpr int RSC = C * 2 + 16, RSB = CB * 2 + 16;
     constexpr int KSC = C / 16, KSB = CB / 16;
     const long long e = c.HW + 1;                   // table entries per (rt, qd, h)
@@ -450,18 +474,18 @@ __device__ __forceinline__ void bottleneck(Ctx& c, const Col& k, WRing<G::NW, G:
     // LN1 -> image -> c1 (1x1, C -> CB)
     ln_to_image<G::NRCW, G::NW>(c, k, gb1, X, C, RSC);
     zero_acc<G::NRBW>(a1);
-    conv_lds<G, KSC, 1, G::NRB, G::NRBW, RSC>(c, k, ring, a1, first_stage_frags(9 * KSB, G::NRB, G::SM));
+    conv_lds<G, KSC, 1, G::NRB, G::NRBW, RSC>(c, k, ring, a1, BS::c2(0), BS::c2(1));
     // LN2 -> image -> c2 (3x3), LN3 -> image -> c3 (3x3); the image is consumed before a1 is rewritten
 #pragma unroll
     for (int layer = 0; layer < 2; layer++) {
         ln_to_image<G::NRBW, G::NW>(c, k, layer == 0 ? gb2 : gb3, a1, CB, RSB);
         zero_acc<G::NRBW>(a1);
-        conv_lds<G, KSB, 9, G::NRB, G::NRBW, RSB>(
-            c, k, ring, a1, layer == 0 ? first_stage_frags(9 * KSB, G::NRB, G::SM) : first_stage_frags(KSB, G::NRC, G::SM));
+        conv_lds<G, KSB, 9, G::NRB, G::NRBW, RSB>(c, k, ring, a1, layer == 0 ? BS::c2(0) : BS::c4(0),
+                                                  layer == 0 ? BS::c2(1) : (BS::n4 > 1 ? BS::c4(1) : nx0));
     }
     // LN4 -> image -> c4 (1x1, CB -> C) accumulated into X
     ln_to_image<G::NRBW, G::NW>(c, k, gb4, a1, CB, RSB);
-    conv_lds<G, KSB, 1, G::NRC, G::NRCW, RSB>(c, k, ring, X, next_nf);
+    conv_lds<G, KSB, 1, G::NRC, G::NRCW, RSB>(c, k, ring, X, nx0, nx1);
 }
 
 // ---- shared prologue: per-board meta data and per-lane column info -----------------------------
@@ -563,7 +587,7 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_seg(NetDims d, TowerDev tw, H
     constexpr int CIN0 = IN == IN_OBS ? 32 : C + 16;  // input channels of conv0, padded to 16
     constexpr int KS0 = CIN0 / 16;
     constexpr int RS0 = CIN0 * 2 + 16;
-    constexpr int FS_C1 = first_stage_frags(C / 16, G::NRB, G::SM);
+    using BS = BlockStages<G>;
     const int tid = threadIdx.x;
     Ctx c;
     ctx_init<G>(c, smem, L, d, NB);
@@ -577,12 +601,17 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_seg(NetDims d, TowerDev tw, H
     f32x16 X[NRCW];
     if (IN == IN_X) {
         ring.init(tw.stream + (long long)tw.foff[b0] * 64, smem + L.ring_off, c.wave, c.lane);
-        if (b0 < b1) ring.issue(FS_C1);
+        if (b0 < b1) {
+            ring.issue(BS::open0);
+            ring.issue(BS::open1);
+        }
         x_load<NRCW>(c, k, io.pool, 1, C, X);
         STAMP(c, ST_XLOAD);
     } else {
         ring.init(tw.stream, smem + L.ring_off, c.wave, c.lane);
-        ring.issue(first_stage_frags(9 * KS0, G::NRC, G::SM));
+        static_assert(num_stages(9 * KS0, G::NRC, G::SM) >= 2, "conv0 spans at least two stages");
+        ring.issue(stage_frags(9 * KS0, G::NRC, G::SM, 0));
+        ring.issue(stage_frags(9 * KS0, G::NRC, G::SM, 1));
         // ---------------- input image + conv0 ----------------
         if (IN == IN_OBS) {
             zero_acc<NRCW>(X);
@@ -618,13 +647,13 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_seg(NetDims d, TowerDev tw, H
                 *reinterpret_cast<bf16x8*>(img + k.col * RS0 + (C + 8 * c.h) * 2) = pack8(&y[0]);
             }
         }
-        conv_lds<G, KS0, 9, G::NRC, NRCW, RS0>(c, k, ring, X, b0 < b1 ? FS_C1 : 0);
+        conv_lds<G, KS0, 9, G::NRC, NRCW, RS0>(c, k, ring, X, b0 < b1 ? BS::open0 : 0, b0 < b1 ? BS::open1 : 0);
     }
 
     {
         const u32x4* gbase = tw.gb;
         for (int blk = b0; blk < b1; blk++)
-            bottleneck<G>(c, k, ring, gbase + tw.gboff[blk], X, blk + 1 < b1 ? FS_C1 : 0);
+            bottleneck<G>(c, k, ring, gbase + tw.gboff[blk], X, blk + 1 < b1);
     }
 
     if (OUT == OUT_X) {
@@ -832,7 +861,7 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_bcast(NetDims d, TowerDev tw,
     constexpr int QT = (KSB + 1) / 2, KP = 16 * KSB;
     constexpr int RS = C * 2 + 16;
     constexpr int KSC = C / 16;
-    constexpr int FS = first_stage_frags(KSC, NRC, G::SM);
+    constexpr int FS0 = stage_frags(KSC, NRC, G::SM, 0), FS1 = stage_frags(KSC, NRC, G::SM, 1);
     Ctx c;
     ctx_init<G>(c, smem, L, d, NB);
     Col k;
@@ -848,7 +877,8 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_bcast(NetDims d, TowerDev tw,
     char* img = smem + L.img_off;
     WRing<G::NW, G::SM> ring;
     ring.init(tw.stream + (long long)tw.foff[blk] * 64, smem + L.ring_off, c.wave, c.lane);
-    ring.issue(FS);
+    ring.issue(FS0);
+    ring.issue(FS1);
     f32x16 X[NRCW];
     x_load<NRCW>(c, k, io.pool, 1, C, X);
     {
@@ -856,7 +886,7 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_bcast(NetDims d, TowerDev tw,
         f32x16 a[NRCW];
         ln_to_image<NRCW, G::NW>(c, k, gb1, X, C, RS);
         zero_acc<NRCW>(a);
-        conv_lds<G, KSC, 1, NRC, NRCW, RS>(c, k, ring, a, 0);
+        conv_lds<G, KSC, 1, NRC, NRCW, RS>(c, k, ring, a, 0, 0);
         STAMP(c, ST_OTHER);
         // LN2 + ReLU -> bf16 -> transposed image TB (the statistics barrier proves that every wave has
         // finished c1, so the ring under TB is dead)
@@ -987,9 +1017,10 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_bcast(NetDims d, TowerDev tw,
     lds_barrier();   // image complete, TB dead: region 2 is the ring again
     STAMP(c, ST_BCAST);
     // c2: 1x1 conv C -> C on the image (own columns), accumulated into X (re-read: it was not held in registers)
-    ring.issue(FS);
+    ring.issue(FS0);
+    ring.issue(FS1);
     x_load<NRCW>(c, k, io.pool, 1, C, X);
-    conv_lds<G, KSC, 1, NRC, NRCW, RS>(c, k, ring, X, 0);
+    conv_lds<G, KSC, 1, NRC, NRCW, RS>(c, k, ring, X, 0, 0);
     x_store<NRCW>(c, k, io.pool, C, X);
     STAMP(c, ST_XSTORE);
     STAMP_PRINT(c, "bcast");
@@ -1091,7 +1122,7 @@ LdsPlan make_plan_seg(const NetDims& d, int COLS, int NW, int SM) {
     const int rs0 = (d.C + 16) * 2 + 16;
     // the ring comes first: LDS-DMA destinations stay below 64 KiB
     L.ring_off = 0;
-    L.img_off = 2 * SM * 1024;
+    L.img_off = NSLOT * SM * 1024;
     int end = L.img_off + align16(COLS * rs0);
     L.head_off = 0;
     plan_tail(L, end, NW);
@@ -1104,7 +1135,7 @@ LdsPlan make_plan_bcast(const NetDims& d, int COLS, int NB, int NW, int SM) {
     L.kp = (d.HW + 15) / 16 * 16;
     L.qt = (d.HW + 31) / 32;
     L.tbs = (NB * L.kp + 8) * 2;
-    const int ring = 2 * SM * 1024, tbb = align16(d.C * L.tbs);
+    const int ring = NSLOT * SM * 1024, tbb = align16(d.C * L.tbs);
     L.ring_off = 0;
     L.tb_off = 0;
     L.img_off = ring > tbb ? ring : tbb;
@@ -1146,7 +1177,7 @@ MfmaNet* mfma_create(const NetDims& d, int /*max_batch*/, std::string* err) {
     // for the 2x3, 2x4 and 2x8 grids, which trade column packing for a second workgroup per CU).  MZ_GEOM picks
     // one of the other grids (diagnostics).
     struct GeomDesc { int WR, NW, SM; };
-    static const GeomDesc kGeom[5] = {{1, 8, 32}, {2, 6, 16}, {2, 8, 16}, {2, 8, 32}, {2, 16, 32}};
+    static const GeomDesc kGeom[5] = {{1, 8, 24}, {2, 6, 16}, {2, 8, 16}, {2, 8, 24}, {2, 16, 32}};
     if (d.C == 256) {
         n->geom = 3;
     } else {
@@ -1377,8 +1408,8 @@ int mfma_forward(MfmaNet* n, hipStream_t st, bool initial, const NetDims& d, con
         return -1;
     }
     switch (n->geom) {
-        case 0: return forward_t<Geo<128, 64, 1, 8, 32, 2>>(n, st, initial, d, io);
-        default: return forward_t<Geo<256, 128, 2, 8, 32, 2>>(n, st, initial, d, io);
+        case 0: return forward_t<Geo<128, 64, 1, 8, 24, 2>>(n, st, initial, d, io);
+        default: return forward_t<Geo<256, 128, 2, 8, 24, 2>>(n, st, initial, d, io);
     }
 }
 
