@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="go9", choices=sorted(WORKLOADS))
-    ap.add_argument("--games", type=int, default=4096, help="concurrent games per GPU")
+    ap.add_argument("--games", type=int, default=16384, help="concurrent games per GPU (SURVEY.md §8d: B in {1024, 4096, 16384})")
     ap.add_argument("--precision", default="bf16", choices=["fp32", "bf16"])
     ap.add_argument("--cpu-games", type=int, default=1024, help="games in the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -186,6 +186,13 @@ def main():
         mean_path = path_sum / max(sims_total, 1)
         tree_bytes = A * (12 * (mean_path - 2) + 28 + 8 + 20 * (mean_path - 1))
         tree_ms = kernel_ms["tree_select"] + kernel_ms["tree_backup"]
+        # HBM traffic of the dominant launch: PMC numbers (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 passes) are
+        # collected offline by tools/pmc.sh and committed per sample; bench.py scales them to this run's batch.
+        traffic = None
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r1d_traffic_{args.workload}.json")
+        if args.precision == "bf16" and os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f)["bytes_per_sample"] * B
         line = {
             "metric": "MCTS simulations/sec",
             "value": sims_all / dt,
@@ -203,7 +210,8 @@ def main():
                                    f"n={n} simulations, m={m}, C={spec.channels}, R={spec.residuals}",
                        "games_per_gpu": B, "num_simulations": n, "parallelism": f"games sharded x{world}"},
             "roofline": {"bound": "mfma", "kernel": "recurrentInference", "achieved": achieved, "peak": peak,
-                         "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+                         "kernels": "k_seg(conv0+blocks) -> k_bcast -> k_seg(blocks+rescale) -> k_heads",
                          "flops_per_launch": fl["recurrent"] * B, "avg_launch_ms": rec_ms / rec_n},
             "tree_kernels": {"bound": "hbm", "mean_path_len": mean_path, "algorithmic_bytes_per_sim": tree_bytes,
                              "achieved_GBps": (tree_bytes * sims_total / (tree_ms / 1e3) / 1e9) if tree_ms else None,

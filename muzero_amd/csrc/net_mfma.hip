@@ -692,34 +692,33 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_seg(NetDims d, TowerDev tw, H
 }
 
 // ---- PredictionBlock (B/c_mainfunctions/PredictionBlock.java:46-84) ------------------------------
-// One 256-thread workgroup per sample, many workgroups per CU: the heads are small latency chains
+// One 256-thread workgroup per HS = 4 samples, many workgroups per CU: the heads are small latency chains
 // (1x1 convs -> LayerNorm -> linears -> softmax / tanh), so they run at high occupancy off the freshly
-// written hidden state instead of serialising the big workgroups of the tower kernels.  All fp32: the
-// per-board LayerNorm over a single HW-value channel amplifies rounding of whatever feeds it.
+// written hidden state instead of serialising the big workgroups of the tower kernels.  Wave s owns sample
+// s for the convs, the LayerNorms and the outputs (no workgroup barrier there); the two linears are shared
+// work: an item = one output of one K chunk, its weights loaded once and applied to all four samples.
+// All fp32: the per-board LayerNorm over a single HW-value channel amplifies rounding of whatever feeds it.
 constexpr int HT = 256;      // threads
+constexpr int HS = 4;        // samples per workgroup (= waves)
 constexpr int HKC = 32;      // K chunk of the two linears
 constexpr int HPMAX = 128;   // cells per sample upper bound (HW <= 96)
 __global__ __launch_bounds__(HT) void k_heads(NetDims d, HeadDev hd, NetIO io) {
-    const int g = blockIdx.x;
-    if (g >= io.B || (io.active && !io.active[g])) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int HW = d.HW, C = d.C, A = d.A;
     extern __shared__ __attribute__((aligned(16))) char hsm[];
-    float* red = reinterpret_cast<float*>(hsm);   // [4 waves][3][HPMAX] partial head-conv outputs
-    float* feat = red + 4 * 3 * HPMAX;            // policy features [2*HW], then value features [HW]
-    float* stat = feat + 3 * HPMAX;               // [8..15]: wave partials of the LayerNorm sums
-    float* lgt = stat + 32;                       // [A]
-    float* hv = lgt + A;                          // [C]
-    float* part = hv + C;                         // K-chunk partials: [n1][A] then [n2][C]
     const int K1 = 2 * HW, n1 = (K1 + HKC - 1) / HKC, n2 = (HW + HKC - 1) / HKC;
     const int items1 = n1 * A, items = items1 + n2 * C;
-    const float* h = io.pool + (long long)io.dst_slot[g] * C * HW;
+    float* feat = reinterpret_cast<float*>(hsm);  // [HS][3*HPMAX]: policy features [2*HW], then value features [HW]
+    float* lgt = feat + HS * 3 * HPMAX;           // [HS][A]
+    float* hv = lgt + HS * A;                     // [HS][C]
+    float* part = hv + HS * C;                    // [HS][items] K-chunk partials: [n1][A] then [n2][C]
+    const int g = blockIdx.x * HS + wave;         // this wave's sample
+    const bool live = g < io.B && (!io.active || io.active[g]);
 
     // weights of this thread's first linear item: requested before anything else
     struct Item {
         const float* w;
-        const float* f;
-        int nout, kn;
+        int foff, nout, kn;
     };
     auto item = [&](int it) {
         const bool pol = it < items1;
@@ -728,7 +727,7 @@ __global__ __launch_bounds__(HT) void k_heads(NetDims d, HeadDev hd, NetIO io) {
         const int ck = j / nout, o = j - ck * nout;
         Item r;
         r.w = (pol ? hd.pfcw : hd.vfc1w) + (long long)(ck * HKC) * nout + o;
-        r.f = (pol ? feat : feat + K1) + ck * HKC;
+        r.foff = (pol ? 0 : K1) + ck * HKC;
         r.nout = nout;
         r.kn = K - ck * HKC;
         return r;
@@ -739,63 +738,49 @@ __global__ __launch_bounds__(HT) void k_heads(NetDims d, HeadDev hd, NetIO io) {
 #pragma unroll
         for (int i = 0; i < HKC; i++) wv[i] = i < q.kn ? q.w[(long long)i * q.nout] : 0.f;
     }
-    // 1x1 convs C -> {policy 0, policy 1, value}: wave w takes channels w, w+4, ...; lane l the cells l, l+64
+    // 1x1 convs C -> {policy 0, policy 1, value} and their LayerNorms, wave-local: lane l holds the cells l, l+64
     {
         float a00 = 0.f, a01 = 0.f, a02 = 0.f, a10 = 0.f, a11 = 0.f, a12 = 0.f;
         const bool v0 = lane < HW, v1 = lane + 64 < HW;
-        const float* h0 = h + (v0 ? lane : 0);
-        const float* h1 = h + (v1 ? lane + 64 : 0);
-#pragma unroll 8
-        for (int ch = wave; ch < C; ch += 4) {
-            const float x0 = h0[ch * HW], x1 = h1[ch * HW];
-            const float w0 = hd.hconv[ch], w1 = hd.hconv[C + ch], w2 = hd.hconv[2 * C + ch];
-            a00 = fmaf(x0, w0, a00);
-            a01 = fmaf(x0, w1, a01);
-            a02 = fmaf(x0, w2, a02);
-            a10 = fmaf(x1, w0, a10);
-            a11 = fmaf(x1, w1, a11);
-            a12 = fmaf(x1, w2, a12);
+        if (live) {
+            const float* h = io.pool + (long long)io.dst_slot[g] * C * HW;
+            const float* h0 = h + (v0 ? lane : 0);
+            const float* h1 = h + (v1 ? lane + 64 : 0);
+#pragma unroll 16
+            for (int ch = 0; ch < C; ch++) {
+                const float x0 = h0[ch * HW], x1 = h1[ch * HW];
+                const float w0 = hd.hconv[ch], w1 = hd.hconv[C + ch], w2 = hd.hconv[2 * C + ch];
+                a00 = fmaf(x0, w0, a00);
+                a01 = fmaf(x0, w1, a01);
+                a02 = fmaf(x0, w2, a02);
+                a10 = fmaf(x1, w0, a10);
+                a11 = fmaf(x1, w1, a11);
+                a12 = fmaf(x1, w2, a12);
+            }
         }
-        float* r = red + wave * 3 * HPMAX;
-        r[lane] = a00;
-        r[HPMAX + lane] = a01;
-        r[2 * HPMAX + lane] = a02;
-        r[64 + lane] = a10;
-        r[HPMAX + 64 + lane] = a11;
-        r[2 * HPMAX + 64 + lane] = a12;
-    }
-    __syncthreads();
-    // LayerNorm over (2, HW) for the policy features and over (1, HW) for the value features
-    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
-    const bool own = tid < HW;   // waves 0 and 1
-    if (tid < HPMAX) {
-        for (int w = 0; w < 4; w++) {
-            c0 += red[w * 3 * HPMAX + tid];
-            c1 += red[w * 3 * HPMAX + HPMAX + tid];
-            c2 += red[w * 3 * HPMAX + 2 * HPMAX + tid];
-        }
-        float s = own ? c0 + c1 : 0.f, q = own ? c0 * c0 + c1 * c1 : 0.f;
-        float vs = own ? c2 : 0.f, vq = own ? c2 * c2 : 0.f;
+        // LayerNorm over (2, HW) for the policy features and over (1, HW) for the value features
+        float s = (v0 ? a00 + a01 : 0.f) + (v1 ? a10 + a11 : 0.f);
+        float q = (v0 ? a00 * a00 + a01 * a01 : 0.f) + (v1 ? a10 * a10 + a11 * a11 : 0.f);
+        float vs = (v0 ? a02 : 0.f) + (v1 ? a12 : 0.f), vq = (v0 ? a02 * a02 : 0.f) + (v1 ? a12 * a12 : 0.f);
         s = wave_red<0>(s);
         q = wave_red<0>(q);
         vs = wave_red<0>(vs);
         vq = wave_red<0>(vq);
-        if (lane == 0) {
-            stat[8 + 4 * wave] = s;
-            stat[9 + 4 * wave] = q;
-            stat[10 + 4 * wave] = vs;
-            stat[11 + 4 * wave] = vq;
-        }
-    }
-    __syncthreads();
-    if (own) {
-        const float s = stat[8] + stat[12], q = stat[9] + stat[13], vs = stat[10] + stat[14], vq = stat[11] + stat[15];
         const float pm = s / (float)(2 * HW), pr = __builtin_amdgcn_rsqf(fmaxf(q / (float)(2 * HW) - pm * pm, 0.f) + 1e-5f);
         const float vm = vs / (float)HW, vr = __builtin_amdgcn_rsqf(fmaxf(vq / (float)HW - vm * vm, 0.f) + 1e-5f);
-        const int p = tid;
-        feat[p] = fmaxf((c0 - pm) * pr * hd.plng[p] + hd.plnb[p], 0.f);
-        feat[HW + p] = fmaxf((c1 - pm) * pr * hd.plng[HW + p] + hd.plnb[HW + p], 0.f);
-        feat[K1 + p] = fmaxf((c2 - vm) * vr * hd.vlng[p] + hd.vlnb[p], 0.f);
+        float* f = feat + wave * 3 * HPMAX;
+        if (v0) {
+            const int p = lane;
+            f[p] = fmaxf((a00 - pm) * pr * hd.plng[p] + hd.plnb[p], 0.f);
+            f[HW + p] = fmaxf((a01 - pm) * pr * hd.plng[HW + p] + hd.plnb[HW + p], 0.f);
+            f[K1 + p] = fmaxf((a02 - vm) * vr * hd.vlng[p] + hd.vlnb[p], 0.f);
+        }
+        if (v1) {
+            const int p = lane + 64;
+            f[p] = fmaxf((a10 - pm) * pr * hd.plng[p] + hd.plnb[p], 0.f);
+            f[HW + p] = fmaxf((a11 - pm) * pr * hd.plng[HW + p] + hd.plnb[HW + p], 0.f);
+            f[K1 + p] = fmaxf((a12 - vm) * vr * hd.vlng[p] + hd.vlnb[p], 0.f);
+        }
     }
     __syncthreads();
     // the two linears, split over K into chunks of HKC; chunk partials are summed in a fixed order
@@ -805,49 +790,54 @@ __global__ __launch_bounds__(HT) void k_heads(NetDims d, HeadDev hd, NetIO io) {
 #pragma unroll
             for (int i = 0; i < HKC; i++) wv[i] = i < q.kn ? q.w[(long long)i * q.nout] : 0.f;
         }
-        float acc = 0.f;
 #pragma unroll
-        for (int i = 0; i < HKC; i++) acc = fmaf(i < q.kn ? q.f[i] : 0.f, wv[i], acc);
-        part[it] = acc;
+        for (int sm = 0; sm < HS; sm++) {
+            const float* f = feat + sm * 3 * HPMAX + q.foff;
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < HKC; i++) acc = fmaf(i < q.kn ? f[i] : 0.f, wv[i], acc);
+            part[sm * items + it] = acc;
+        }
     }
     __syncthreads();
-    for (int a = tid; a < A; a += HT) {
+    // outputs of sample `wave`
+    const float* pt = part + wave * items;
+    float* lg = lgt + wave * A;
+    float* hvw = hv + wave * C;
+    for (int a = lane; a < A; a += 64) {
         float acc = hd.pfcb[a];
-        for (int ck = 0; ck < n1; ck++) acc += part[ck * A + a];
-        lgt[a] = acc;
+        for (int ck = 0; ck < n1; ck++) acc += pt[ck * A + a];
+        lg[a] = acc;
     }
-    for (int ch = tid; ch < C; ch += HT) {
+    float pv = 0.f;
+    for (int ch = lane; ch < C; ch += 64) {
         float acc = hd.vfc1b[ch];
-        for (int ck = 0; ck < n2; ck++) acc += part[items1 + ck * C + ch];
-        hv[ch] = fmaxf(acc, 0.f);
+        for (int ck = 0; ck < n2; ck++) acc += pt[items1 + ck * C + ch];
+        pv = fmaf(fmaxf(acc, 0.f), hd.vfc2w[ch], pv);
     }
-    __syncthreads();
-    if (wave == 0) {
-        float mx = -INFINITY;
-        for (int a = lane; a < A; a += 64) mx = fmaxf(mx, lgt[a]);
-        mx = wave_red<2>(mx);
-        float se = 0.f;
-        for (int a = lane; a < A; a += 64) se += expf(lgt[a] - mx);
-        se = wave_red<0>(se);
-        for (int a = lane; a < A; a += 64) {
-            const float l = lgt[a];
-            io.logits[(long long)g * A + a] = l;
-            io.policy[(long long)g * A + a] = expf(l - mx) / se;
-        }
-    } else if (wave == 1) {
-        float pv = 0.f;
-        for (int ch = lane; ch < C; ch += 64) pv = fmaf(hv[ch], hd.vfc2w[ch], pv);
-        pv = wave_red<0>(pv);
-        if (lane == 0) {
-            float v = pv + hd.vfc2b[0];
-            if (d.two_players) v = tanhf(v);
-            io.value[g] = d.value_scale * (double)v;
-        }
+    (void)hvw;
+    if (!live) return;
+    float mx = -INFINITY;
+    for (int a = lane; a < A; a += 64) mx = fmaxf(mx, lg[a]);   // same lane wrote lg[a]
+    mx = wave_red<2>(mx);
+    float se = 0.f;
+    for (int a = lane; a < A; a += 64) se += expf(lg[a] - mx);
+    se = wave_red<0>(se);
+    for (int a = lane; a < A; a += 64) {
+        const float l = lg[a];
+        io.logits[(long long)g * A + a] = l;
+        io.policy[(long long)g * A + a] = expf(l - mx) / se;
+    }
+    pv = wave_red<0>(pv);
+    if (lane == 0) {
+        float v = pv + hd.vfc2b[0];
+        if (d.two_players) v = tanhf(v);
+        io.value[g] = d.value_scale * (double)v;
     }
 }
 size_t heads_lds_bytes(const NetDims& d) {
     const int n1 = (2 * d.HW + HKC - 1) / HKC, n2 = (d.HW + HKC - 1) / HKC;
-    return (size_t)(4 * 3 * HPMAX + 3 * HPMAX + 32 + d.A + d.C + n1 * d.A + n2 * d.C) * 4;
+    return (size_t)HS * (3 * HPMAX + d.A + d.C + n1 * d.A + n2 * d.C) * 4;
 }
 
 // ---- BroadcastResidualBlock: x + c2(relu(LN(bcast(relu(LN(c1(relu(LN(x))))))))) ------------------
@@ -1384,7 +1374,7 @@ int forward_t(MfmaNet* n, hipStream_t st, bool initial, const NetDims& d, const 
             if (last) launch_seg<G, IN_X, OUT_FINAL>(n, st, grid, d, tw, io, b, e);
             else launch_seg<G, IN_X, OUT_X>(n, st, grid, d, tw, io, b, e);
         }
-        if (last) hipLaunchKernelGGL(k_heads, dim3(io.B), dim3(HT), heads_lds_bytes(d), st, d, n->hd, io);
+        if (last) hipLaunchKernelGGL(k_heads, dim3((io.B + HS - 1) / HS), dim3(HT), heads_lds_bytes(d), st, d, n->hd, io);
         first = false;
         if (last || (dbg_stop >= 0 && dbg_stop == e)) break;
         switch (n->Lbc.kp / 16) {
