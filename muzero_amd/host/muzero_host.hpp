@@ -2,8 +2,8 @@
 // reference's host language (Java 21) has no toolchain in this image.  It mirrors the reference's
 // plugin / operator interface for the self-play path, same names and argument meaning, so a reader
 // of the reference finds: Action, OneOfTwoPlayer, Observation, ObservationModelInput, GameDTO,
-// Environment, Game (+ TicTacToe / PegSolitair / Go plugins), NetworkIO, ModelService, PlanAction,
-// PlayParameters, PlayService.  Paths below are relative to
+// Environment, Game (+ the TicTacToe plugin), NetworkIO, ModelService, PlanAction, PlayParameters,
+// PlayService.  Paths below are relative to
 //   P/ = platform/src/main/java/ai/enpasos/muzero/platform/      G/ = games/<game>/src/main/java/ai/enpasos/muzero/<game>/
 //
 // What differs by design (MI355X-first): the reference runs one thread per game and meets the other
@@ -85,6 +85,7 @@ class Game;
 // functions come from G/../resources/application.yml of each game.
 struct MuZeroConfig {
     std::string game;  // "tictactoe" | "go5" | "go9" | "pegsolitair"
+    bool hybridTraining = false;  // trainingTypeKey == HYBRID (MuZeroConfig.java:343-362)
     PlayerMode playerMode = PlayerMode::TWO_PLAYERS;
     int boardHeight = 3, boardWidth = 3, actionSpaceSize = 9;
     int numObservationLayers = 3, numActionLayers = 1;
@@ -205,101 +206,11 @@ public:
     void connectToEnvironment() override;
 };
 
-// G(pegsolitair)/config/environment/Board.java, Point.java, Direction.java, Jump.java, NeighborMap.java
-struct PegBoard {
-    uint8_t peg[8][8]{};  // 1-based [row][col]; value 1 = peg, 0 = hole (only where inRange)
-    PegBoard();
-    static bool outOfBounds(int row, int col);
-    static bool inRange(int row, int col) { return !outOfBounds(row, col); }
-    struct Jump { int row, col, direction; };  // fromPoint + Direction ordinal (N,E,S,W)
-    std::vector<Jump> getLegalJumps() const;
-    void applyJump(const Jump& j);
-    float getScore() const;
-    bool isOnePegInTheMiddle() const { return peg[4][4] != 0; }
-    int numPegs() const;
-    std::string render() const;
-};
-// G(pegsolitair)/config/PegSolitairEnvironment.java:36-83, PegSolitairAdapter.java:14-76
-class PegSolitairEnvironment : public Environment {
-public:
-    explicit PegSolitairEnvironment(const MuZeroConfig&) {}
-    float step(const Action& action) override;
-    std::vector<Action> getLegalActions() const override;
-    Observation getObservation() const override;
-    bool isTerminal() const override;
-    std::string render() const override { return board.render(); }
-    PegBoard board;
-};
-// G(pegsolitair)/config/PegSolitairGame.java:42-111
-class PegSolitairGame : public Game {
-public:
-    using Game::Game;
-    using Game::getObservationModelInput;
-    bool terminal() const override;
-    const OneOfTwoPlayer* toPlay() const override { return nullptr; }
-    ObservationModelInput getObservationModelInput(int inputTime) const override;
-    void connectToEnvironment() override;
-};
-
-// G(go)/config/environment/GoBoard.java, GameState.java, scoring/TerritoryCalculator.java, GameResult.java.
-// Compact restatement: the board is a grid of colours, strings and liberties are recomputed by flood
-// fill; the ko history stores (player, position) pairs exactly instead of Zobrist hashes.
-struct GoBoard {
-    int size = 0;
-    std::vector<int8_t> grid;  // 0 empty, 1 black, 2 white; index (row-1)*size + (col-1)
-    int blackCaptures = 0, whiteCaptures = 0;
-    explicit GoBoard(int size = 0) : size(size), grid(static_cast<size_t>(size) * size, 0) {}
-    int at(int row, int col) const { return grid[(row - 1) * size + col - 1]; }
-    bool inBounds(int row, int col) const { return 1 <= row && row <= size && 1 <= col && col <= size; }
-    GoBoard placeStone(int player, int row, int col) const;           // GoBoard.java:101-138,164-212
-    bool isSelfCapture(int player, int row, int col) const;           // :141-162
-    bool willCapture(int player, int row, int col) const;             // :267-274
-    bool doesMoveFillEye(int player, int row, int col) const;         // :219-262
-    int numLiberties(int row, int col, std::vector<int>* stones = nullptr) const;
-};
-struct GoGameResult {  // scoring/GameResult.java:28-113
-    int numBlackStones = 0, numWhiteStones = 0, numBlackTerritory = 0, numWhiteTerritory = 0;
-    int numBlackCaptures = 0, numWhiteCaptures = 0, numDame = 0;
-    float komi = 0;
-    static GoGameResult apply(const GoBoard& board, float komi);
-    int blackPoints() const { return numBlackTerritory + numBlackStones; }
-    int whitePoints() const { return numWhiteTerritory + numWhiteStones; }
-    float blackWinningMargin() const { return blackPoints() - (whitePoints() + komi); }
-};
-// G(go)/config/GoEnvironment.java:45-127 over GameState.java:30-149
-class GoEnvironment : public Environment {
-public:
-    explicit GoEnvironment(const MuZeroConfig& c);
-    float step(const Action& action) override;
-    std::vector<Action> getLegalActions() const override;
-    Observation getObservation() const override;
-    bool isTerminal() const override;
-    std::string render() const override;
-    bool isValidMove(int row, int col) const;  // GameState.java:108-116
-    const GoBoard& getBoard() const { return board; }
-    int getNextPlayer() const { return nextPlayer; }
-    const GoGameResult* getResult() const { return hasResult ? &result : nullptr; }
-
-private:
-    int size, A;
-    float komi;
-    GoBoard board;
-    int nextPlayer = 1;                 // 1 black, 2 white
-    int lastMove = 0, secondLastMove = 0;  // 0 none, 1 play, 2 pass
-    std::vector<std::pair<int, std::vector<int8_t>>> allPreviousStates;
-    GoGameResult result;
-    bool hasResult = false;
-};
-// G(go)/config/GoGame.java:59-126
-class GoGame : public Game {
-public:
-    using Game::Game;
-    using Game::getObservationModelInput;
-    bool terminal() const override;
-    const OneOfTwoPlayer* toPlay() const override;
-    ObservationModelInput getObservationModelInput(int inputTime) const override;
-    void connectToEnvironment() override;
-};
+// The PegSolitair and Go plugins (G(pegsolitair)/config/*, G(go)/config/*) are not restated here: game rules are
+// off the hot path (the environment is stepped once per real move on the host) and stay in the
+// reference's Java modules behind the same Game / Environment interface.  MuZeroConfig::pegsolitair() and
+// ::go(size) carry their network and search parameters so that synthetic positions of those shapes can be
+// searched (tests, bench.py); MuZeroConfig::newGame throws MuZeroException for them.
 
 // ---- random sources --------------------------------------------------------------------------
 // Stand-in for ThreadLocalRandom / SSJ DirichletGen (GumbelFunctions.java:48-54, Functions.java:28-37,
@@ -371,8 +282,6 @@ public:
     // Returns the chosen action per game and appends to each GameDTO what planAction +
     // storeSearchStatistics + selectAction append.
     std::vector<Action> planActions(const std::vector<Game*>& games, const PlayParameters& p);
-    // PlanAction.java:34-65
-    void justReplayActionsWithInitialInference(const std::vector<Game*>& games);
     int64_t simulationsRun = 0;
 
 private:
@@ -386,8 +295,7 @@ public:
     PlayService(ModelService& modelService, uint64_t seed) : modelService(modelService), planAction(modelService, seed), rng(seed ^ 0x9E3779B97F4A7C15ull) {}
     std::vector<std::unique_ptr<Game>> playNewGames(int numGames, PlayParameters p);
     void playGames(const std::vector<Game*>& games, PlayParameters p);
-    void reanalyseGames(const std::vector<Game*>& games, PlayParameters p);            // PlayService.java:53-76
-    void justReplayGamesWithInitialInference(const std::vector<Game*>& games);         // :78-85
+    // reanalyseGames / justReplayGamesWithInitialInference (PlayService.java:53-85) are SURVEY.md §8f row N4 (next)
     void hybridConfiguration(const std::vector<Game*>& games, int gameLength);         // :92-103
     int maxGameLength = 0;  // gameBuffer.getMaxGameLength()
     int64_t simulationsRun() const { return planAction.simulationsRun; }
