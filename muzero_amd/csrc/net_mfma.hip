@@ -60,7 +60,7 @@ constexpr int ZROW_BYTES = 1024;
 
 #if defined(MZ_STAMPS)  // diagnostic build: per-phase cycle counts of workgroup 0 (waves 0 and 7), printed by the kernel
 #define STAMP(c, i) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); (c).st_acc[i] += (unsigned)(t_ - (c).st_last); (c).st_last = t_; } while (0)
-#define STAMP_PRINT(c, name) do { if (blockIdx.x == 0 && ((c).wave == 0 || (c).wave == 7) && (c).lane == 0) \
+#define STAMP_PRINT(c, name) do { if (blockIdx.x == 0 && ((c).wave == 0 || (c).wave == 4 || (c).wave == 7) && (c).lane == 0) \
     printf("%s w%d: stats %u norm %u acquire %u mma %u xload %u xstore %u rescale %u head %u other %u bcast %u | hconv %u hln %u hfc %u\n", name, (c).wave, \
            (c).st_acc[0], (c).st_acc[1], (c).st_acc[2], (c).st_acc[3], (c).st_acc[4], (c).st_acc[5], (c).st_acc[6], (c).st_acc[7], (c).st_acc[8], (c).st_acc[9], (c).st_acc[10], (c).st_acc[11], (c).st_acc[12]); } while (0)
 #else
@@ -181,25 +181,31 @@ template <int NW, int SM>
 struct WRing {
     const char* gptr;  // next fragment to load (wave-uniform)
     char* lds;         // ring base
+    unsigned ldsoff;   // the same as an LDS byte address (what M0 takes)
     int ld_idx, rd_idx, wave;
     unsigned lane16;
     __device__ __forceinline__ void init(const u32x4* stream, char* ring, int wave_, int lane) {
         gptr = reinterpret_cast<const char*>(stream);
         lds = ring;
+        ldsoff = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)ring;
         ld_idx = rd_idx = 0;
         wave = wave_;
         lane16 = (unsigned)lane * 16u;
     }
     __device__ __forceinline__ void issue(int nf) {
         if (nf == 0) return;   // nothing follows: the slot stays with the next real issue()
-        char* dst = lds + ld_idx * (SM * 1024);
+        // The DMA is issued from inline asm on purpose: with __builtin_amdgcn_global_load_lds in flight hipcc's
+        // s_waitcnt pass turns every LDS-read wait of the MFMA loops into lgkmcnt(0), which undoes their software
+        // pipelining.  M0 = LDS byte address of the fragment (wave-uniform), written in the same statement.
+        const unsigned dst = ldsoff + ld_idx * (SM * 1024);
 #pragma unroll
         for (int i = 0; i < (SM + NW - 1) / NW; i++) {
             const int f = wave + NW * i;
-            if (f < nf)
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void*)(gptr + (size_t)f * 1024 + lane16),
-                    (__attribute__((address_space(3))) void*)(dst + f * 1024), 16, 0, 0);
+            if (f < nf) {
+                const char* gp = gptr + (size_t)f * 1024 + lane16;
+                const unsigned m0v = dst + f * 1024;
+                asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp), "s"(m0v) : "memory");
+            }
         }
         gptr += (size_t)nf * 1024;
         ld_idx = ld_idx == NSLOT - 1 ? 0 : ld_idx + 1;
@@ -406,15 +412,8 @@ __device__ __forceinline__ void conv_lds(Ctx& c, const Col& k, WRing<G::NW, G::S
     const char* img = c.smem + c.L.img_off;
     const char* zrow = c.smem + c.L.zrow_off;
     const char* slot = nullptr;
-#pragma unroll
-    for (int kk = 0; kk < KK; kk++) {
-        if (kk % SK == 0) {
-            STAMP(c, kk == 0 ? ST_OTHER : ST_MMA);
-            slot = ring.acquire() + (c.wr * NROW) * 1024 + c.lane * 16;
-            STAMP(c, ST_ACQ);
-            const int j = kk / SK + 2;   // the stage requested now
-            ring.issue(j < NST ? stage_frags(KK, NROT, G::SM, j) : (j == NST ? after1 : after2));
-        }
+    // operands of k-step kk: B from the image (own column, or the tap's neighbour row), A from the ring slot
+    auto load_ops = [&](int kk, bf16x8& b, bf16x8(&a)[NROW]) {
         const int t = kk / KS, ks = kk % KS;
         const char* row;
         if (TAPS == 9) {
@@ -423,12 +422,36 @@ __device__ __forceinline__ void conv_lds(Ctx& c, const Col& k, WRing<G::NW, G::S
         } else {
             row = img + k.col * RS;
         }
-        const bf16x8 b = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(row + (16 * ks + 8 * c.h) * 2));
+        b = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(row + (16 * ks + 8 * c.h) * 2));
 #pragma unroll
-        for (int ro = 0; ro < NROW; ro++) {
-            const bf16x8 a =
-                __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(slot + ((kk % SK) * NROT + ro) * 1024));
-            acc[ro] = MFMA(a, b, acc[ro]);
+        for (int ro = 0; ro < NROW; ro++)
+            a[ro] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(slot + ((kk % SK) * NROT + ro) * 1024));
+    };
+    // Software pipeline: the operands of k-step kk+1 are requested before the MFMAs of kk issue (inside a stage;
+    // a new stage starts with its barrier), so LDS latency hides behind the matrix pipe instead of in front of it.
+    // (Two and three k-steps ahead measured no better; explicit registers, not arrays: indexing by kk % n bloated
+    // the code badly for some n.)
+    bf16x8 bcur, bnxt, acur[NROW], anxt[NROW];
+#pragma unroll
+    for (int kk = 0; kk < KK; kk++) {
+        if (kk % SK == 0) {
+            STAMP(c, kk == 0 ? ST_OTHER : ST_MMA);
+            slot = ring.acquire() + (c.wr * NROW) * 1024 + c.lane * 16;
+            STAMP(c, ST_ACQ);
+            const int j = kk / SK + 2;   // the stage requested now
+            ring.issue(j < NST ? stage_frags(KK, NROT, G::SM, j) : (j == NST ? after1 : after2));
+            load_ops(kk, bcur, acur);
+        }
+        const bool more = kk + 1 < KK && (kk + 1) % SK != 0;
+        if (more) load_ops(kk + 1, bnxt, anxt);
+        __builtin_amdgcn_sched_barrier(0);   // the scheduler would otherwise sink these reads below the MFMAs
+#pragma unroll
+        for (int ro = 0; ro < NROW; ro++) acc[ro] = MFMA(acur[ro], bcur, acc[ro]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) {
+            bcur = bnxt;
+#pragma unroll
+            for (int ro = 0; ro < NROW; ro++) acur[ro] = anxt[ro];
         }
     }
     STAMP(c, ST_MMA);
