@@ -110,3 +110,47 @@ def test_end_to_end_go9_bf16_mfma():
 
 def test_end_to_end_pegsolitair_bf16_mfma():
     _e2e(netspec.spec_pegsolitair(), "pegsolitair", B=8, seed=7, precision=capi.PRECISION_BF16)
+
+
+def test_end_to_end_tictactoe_bf16_mfma():
+    # numChannels 256 grid (2 x 4 waves on 128 columns = 14 boards per workgroup); 33 games = 3 tiles, the last ragged
+    _e2e(netspec.spec_tictactoe(), "tictactoe", B=33, seed=9, precision=capi.PRECISION_BF16)
+
+
+def test_end_to_end_go5_bf16_mfma_dirichlet():
+    # numChannels 256 with a broadcast block (5 boards per workgroup), root noise on
+    _e2e(netspec.spec_go5(), "go5", B=11, seed=10, precision=capi.PRECISION_BF16, frac=0.25)
+
+
+def test_single_game_and_one_legal_action_shortcut_bf16():
+    """Edge cases of PlanAction.planAction: a batch of one game, and games with a single legal action take the
+    shortcut (PlanAction.java:99-101,147-171): no simulation, one-hot policy target, value target = root value."""
+    spec = netspec.spec_go9()
+    c = H.SEARCH_CASES["go9"]
+    w = netspec.random_weights(spec, seed=11)
+    rng = np.random.default_rng(11)
+    B, A = 5, spec.action_space
+    ctx = capi.Context(capi.make_config(spec, c["n"], c["m"], c["c_visit"], known_bounds=c["bounds"], max_games=B,
+                                        precision=capi.PRECISION_BF16))
+    ctx.load_weights(netspec.pack_blob(spec, w))
+    ctx.set_action_cells(netspec.action_cells_board(spec))
+    obs = H.synthetic_obs(rng, spec, B)
+    legal = np.ones((B, A), np.uint8)
+    legal[1] = 0
+    legal[1, 37] = 1            # one option
+    legal[3] = 0
+    legal[3, A - 1] = 1         # only the pass move
+    g = H.gumbel_noise(rng, B, A)
+    got = ctx.search_moves(B, obs, legal, gumbel=g)
+    assert (got["status"] == 0).all()
+    assert got["action"][1] == 37 and got["action"][3] == A - 1
+    assert got["sims_run"][1] == 0 and got["sims_run"][3] == 0
+    assert got["sims_run"][0] == c["n"] and got["sims_run"][2] == c["n"] and got["sims_run"][4] == c["n"]
+    assert got["policy_target"][1, 37] == 1.0 and got["policy_target"][1].sum() == 1.0
+    assert got["root_value_target"][1] == got["root_value_inference"][1] == got["v_mix"][1]
+    assert (got["visit_counts"][[0, 2, 4]].sum(1) == c["n"]).all()
+    # the same first game alone gives the same result as inside the batch (games are independent units)
+    one = ctx.search_moves(1, obs[:1], legal[:1], gumbel=g[:1])
+    assert one["action"][0] == got["action"][0]
+    np.testing.assert_array_equal(one["visit_counts"][0], got["visit_counts"][0])
+    ctx.close()
