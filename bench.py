@@ -218,7 +218,7 @@ def main():
                              "peak_GBps": 8000.0},
             "kernel_ms": {k: round(v, 3) for k, v in kernel_ms.items()},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # timed beside the GPU at N = 1 only
             w_cpu = weights if weights is not None else netspec.random_weights(spec, seed=1)
             v, sims, secs, threads = cpu_baseline(spec, w_cpu, n, m, c_visit, bounds, args.cpu_games, seed=1000)
             line["cpu_baseline"] = {"value": v, "unit": "simulations/s", "cores": threads, "kind": "port",
