@@ -108,6 +108,54 @@ int main() {
     for (double x : d) s += x;
     CHECK(s > 0.999999 && s < 1.000001);   // FunctionsTest.java:19-29 checks only the normalisation
 
+    // JDK semantics restated for the host: HashMap iteration order and Kahan summation
+    {
+        std::vector<int> full9{0, 1, 2, 3, 4, 5, 6, 7, 8};
+        CHECK((javaHashMapOrder(full9) == std::vector<int>{5, 6, 7, 8, 0, 1, 2, 3, 4}));
+        std::vector<int> go(82);
+        for (int i = 0; i < 82; i++) go[i] = i;
+        const std::vector<int> o = javaHashMapOrder(go);
+        CHECK(o.size() == 82 && o[0] == 69 && o[12] == 81 && o[13] == 0 && o[81] == 68);
+        std::vector<double> tiny(11, 1e-16);
+        tiny[0] = 1.0;
+        CHECK(javaDoubleStreamSum(tiny) > 1.0);   // the plain fold loses every 1e-16 and returns exactly 1.0
+    }
+
+    // PlayTest.testMultiGameStarter_FastRule (PlayTest.java:75-85): 1000 games with fastRulesLearning need no network
+    {
+        ModelService noDevice(config);
+        PlayService playService(noDevice, 11);
+        PlayParameters p;
+        p.render = false;
+        p.fastRulesLearning = true;
+        std::vector<std::unique_ptr<Game>> games = playService.playNewGames(1000, p);
+        CHECK(games.size() == 1000);
+        long bad = 0;
+        for (auto& g : games) {
+            const GameDTO& dto = g->getGameDTO();
+            const size_t T = dto.actions.size();
+            if (!g->isDone(false) || T < 5 || T > 9) bad++;
+            if (dto.policyTargets.size() != T || dto.playoutPolicy.size() != T || dto.rootValueTargets.size() != T ||
+                dto.legalActionMaxEntropies.size() != T || !dto.entropies.empty() || !dto.rootValuesFromInitialInference.empty())
+                bad++;
+            for (size_t t = 0; t < T; t++) {
+                int legal = 0;
+                for (uint8_t b : dto.legalActions[t]) legal += b;
+                if (!dto.legalActions[t][dto.actions[t]]) bad++;
+                for (int a = 0; a < 9; a++)
+                    if (dto.policyTargets[t][a] != (dto.legalActions[t][a] ? static_cast<float>(1.0 / legal) : 0.f)) bad++;
+            }
+        }
+        CHECK(bad == 0);
+        bool thrown2 = false;
+        try {
+            noDevice.initialInference(*games[0]);
+        } catch (const MuZeroException&) {
+            thrown2 = true;
+        }
+        CHECK(thrown2);
+    }
+
     std::printf(failures ? "host_rules_test: %d failure(s)\n" : "host_rules_test: ok\n", failures);
     return failures ? 1 : 0;
 }

@@ -232,13 +232,12 @@ void Game::apply(std::initializer_list<int> actionIndices) {
 }
 
 void Game::pseudoApplyFromOriginalGame(const Action& action) {
-    // Game.java:199-205: the action is recorded, observation / reward / legal actions come from the original game
+    // Game.java:199-205: the action is recorded; reward, observation and legal actions come from the original game
     if (!originalGameDTO) throw MuZeroException("replay without an original game");
     gameDTO.actions.push_back(action.getIndex());
-    const size_t t = gameDTO.actions.size();
-    if (t < originalGameDTO->observations.size()) gameDTO.observations.push_back(originalGameDTO->observations[t]);
-    if (t - 1 < originalGameDTO->rewards.size()) gameDTO.rewards.push_back(originalGameDTO->rewards[t - 1]);
-    if (t < originalGameDTO->legalActions.size()) gameDTO.legalActions.push_back(originalGameDTO->legalActions[t]);
+    gameDTO.rewards.push_back(originalGameDTO->rewards.at(gameDTO.rewards.size()));
+    gameDTO.observations.push_back(originalGameDTO->observations.at(gameDTO.observations.size()));
+    gameDTO.legalActions.push_back(originalGameDTO->legalActions.at(gameDTO.legalActions.size()));
     actionApplied = true;
 }
 
@@ -362,6 +361,53 @@ ObservationModelInput TicTacToeGame::getObservationModelInput(int inputTime) con
 
 void TicTacToeGame::connectToEnvironment() { environment.reset(new TicTacToeEnvironment(config)); }
 
+// ---- JDK semantics used on the host ----------------------------------------------------------
+std::vector<int> javaHashMapOrder(const std::vector<int>& keys) {
+    // buckets ascending, insertion order inside a bucket; the table doubles from 16 when size exceeds 0.75 * T and
+    // when a bucket would reach 9 entries while T < 64 (treeifyBin resizes instead of treeifying)
+    size_t T = 16, threshold = 12, size = 0;
+    std::vector<std::vector<int>> tab(T);
+    auto hashOf = [](int idx) {
+        const uint32_t h = static_cast<uint32_t>(59 + idx);
+        return h ^ (h >> 16);
+    };
+    auto resize = [&]() {
+        const size_t oldT = T;
+        T *= 2;
+        threshold *= 2;
+        std::vector<std::vector<int>> nt(T);
+        for (size_t j = 0; j < oldT; j++)
+            for (int k : tab[j]) nt[(hashOf(k) & oldT) == 0 ? j : j + oldT].push_back(k);
+        tab.swap(nt);
+    };
+    for (int k : keys) {
+        std::vector<int>& bin = tab[hashOf(k) & (T - 1)];
+        const size_t existing = bin.size();
+        bin.push_back(k);
+        if (existing >= 8) {
+            if (T >= 64) throw MuZeroException("HashMap bin would treeify: unsupported action space");
+            resize();
+        }
+        if (++size > threshold) resize();
+    }
+    std::vector<int> out;
+    for (const auto& bin : tab) out.insert(out.end(), bin.begin(), bin.end());
+    return out;
+}
+
+double javaDoubleStreamSum(const std::vector<double>& values) {
+    double sum = 0.0, comp = 0.0, simple = 0.0;
+    for (double d : values) {
+        const double tmp = d - comp;
+        const double velvel = sum + tmp;
+        comp = (velvel - sum) - tmp;
+        sum = velvel;
+        simple += d;
+    }
+    const double r = sum - comp;
+    return (std::isnan(r) && std::isinf(simple)) ? simple : r;
+}
+
 // ---- Rng ----------------------------------------------------------------------------------------------------
 uint64_t Rng::next() {  // SplitMix64
     uint64_t z = (state += 0x9E3779B97F4A7C15ull);
@@ -419,9 +465,14 @@ ModelService::ModelService(const MuZeroConfig& config, int maxGames, int precisi
     check(mz_set_action_cells(ctx, cells.data()), "mz_set_action_cells");
 }
 
-ModelService::~ModelService() { mz_destroy(ctx); }
+ModelService::ModelService(const MuZeroConfig& config) : config(config), maxGames_(1 << 30), poolSlots(0) {}
+
+ModelService::~ModelService() {
+    if (ctx) mz_destroy(ctx);
+}
 
 void ModelService::check(int rc, const char* what) {
+    if (!ctx) throw MuZeroException(std::string(what) + ": this ModelService has no device context");
     if (rc != 0) throw MuZeroException(std::string(what) + ": " + mz_last_error(ctx));
 }
 
@@ -430,6 +481,7 @@ void ModelService::loadWeights(const float* blob, size_t count) { check(mz_load_
 NetworkIO ModelService::initialInference(const Game& game) { return initialInference(std::vector<const Game*>{&game})[0]; }
 
 std::vector<NetworkIO> ModelService::initialInference(const std::vector<const Game*>& games) {
+    if (!ctx) throw MuZeroException("inference: this ModelService has no device context");
     const int B = static_cast<int>(games.size()), A = config.actionSpaceSize;
     if (nextSlot + B > poolSlots) throw MuZeroException("hidden-state pool exhausted: raise poolSlots or start a new scope");
     std::vector<float> obs;
@@ -453,6 +505,7 @@ std::vector<NetworkIO> ModelService::initialInference(const std::vector<const Ga
 }
 
 std::vector<NetworkIO> ModelService::recurrentInference(const std::vector<int>& hiddenStates, const std::vector<int>& actions) {
+    if (!ctx) throw MuZeroException("inference: this ModelService has no device context");
     const int B = static_cast<int>(hiddenStates.size()), A = config.actionSpaceSize;
     if (actions.size() != hiddenStates.size()) throw MuZeroException("recurrentInference: one action per hidden state");
     if (nextSlot + B > poolSlots) throw MuZeroException("hidden-state pool exhausted: raise poolSlots or start a new scope");
@@ -474,13 +527,11 @@ std::vector<NetworkIO> ModelService::recurrentInference(const std::vector<int>& 
 
 // ---- PlanAction (P/agent/c_planning/PlanAction.java:68-171), batched -------------------------------------------
 std::vector<Action> PlanAction::planActions(const std::vector<Game*>& games, const PlayParameters& p) {
-    // The branches that do not reach the search (fastRulesLearning, justInitialInferencePolicy) and replay are
-    // SURVEY.md §8f row N4; they raise like any unsupported call in the reference (unchecked MuZeroException).
-    if (p.fastRulesLearning || p.justInitialInferencePolicy || p.replay || p.justReplayWithInitialReference)
-        throw MuZeroException("planActions: fastRulesLearning / justInitialInferencePolicy / replay are not on the device path yet");
     const MuZeroConfig& config = modelService.getConfig();
     const int B = static_cast<int>(games.size()), A = config.actionSpaceSize;
     if (B == 0) return {};
+    if (p.fastRulesLearning) return planActionsFastRules(games, p);
+    if (p.justInitialInferencePolicy) return planActionsJustInitialInference(games, p);
     if (B > modelService.maxGames()) throw MuZeroException("more games than the context was created for");
     const int O = config.numObservationLayers * config.boardHeight * config.boardWidth;
 
@@ -547,11 +598,139 @@ std::vector<Action> PlanAction::planActions(const std::vector<Game*>& games, con
         dto.vMix.push_back(vMix[g]);
         dto.policyTargets.emplace_back(policyTarget.begin() + o, policyTarget.begin() + o + A);
         if (sims[g] > 0) dto.rootEntropyValueTargets.push_back(rootEntropyValueTarget[g]);   // GumbelSearch.java:75-114 only
-        if (playoutAppended[g]) dto.playoutPolicy.emplace_back(playout.begin() + o, playout.begin() + o + A);
-        result[g] = config.newAction(action[g]);
         simulationsRun += sims[g];
+        if (p.replay) {
+            // GumbelSearch.selectAction :365-370 / PlanAction.java:161-163: the search ran, but the move is the original
+            // game's and no playout policy is recorded
+            const size_t a = dto.rootValuesFromInitialInference.size() - 1;
+            if (!games[g]->originalGameDTO) throw MuZeroException("replay without an original game");
+            if (a < games[g]->originalGameDTO->actions.size()) {
+                result[g] = config.newAction(games[g]->originalGameDTO->actions[a]);
+                continue;
+            }
+        }
+        if (playoutAppended[g] && !(p.replay && sims[g] == 0))
+            dto.playoutPolicy.emplace_back(playout.begin() + o, playout.begin() + o + A);
+        result[g] = config.newAction(action[g]);
     }
     return result;
+}
+
+// fastRulesLearning (PlanAction.java:81-84,104-110,134-141; Node.java:289-294; GumbelSearch.java:372-378): no network,
+// uniform priors over the legal actions, the policy target is the prior, the move is root.getRandomAction().
+std::vector<Action> PlanAction::planActionsFastRules(const std::vector<Game*>& games, const PlayParameters& p) {
+    const MuZeroConfig& config = modelService.getConfig();
+    const int A = config.actionSpaceSize;
+    std::vector<Action> result;
+    for (Game* game : games) {
+        GameDTO& dto = game->getGameDTO();
+        const std::vector<Action> la = game->legalActions();
+        if (la.empty()) throw MuZeroException("planAction on a game without legal actions");
+        dto.legalActionMaxEntropies.push_back(static_cast<float>(std::log(static_cast<double>(la.size()))));
+        std::vector<float> policyTarget(A, 0.f);
+        if (la.size() == 1) {  // shortCutForGameWithoutAnOption
+            dto.rootValueTargets.push_back(0.f);
+            dto.vMix.push_back(0.f);
+            policyTarget[la[0].getIndex()] = 1.f;
+            dto.policyTargets.push_back(policyTarget);
+            if (!p.replay) dto.playoutPolicy.push_back(policyTarget);
+            result.push_back(la[0]);
+            continue;
+        }
+        const double prior = 1.0 / static_cast<double>(la.size());
+        dto.rootValueTargets.push_back(0.f);   // root.improvedValue, vmix and improvedEntropyValue are never computed
+        dto.vMix.push_back(0.f);
+        dto.rootEntropyValueTargets.push_back(0.f);
+        for (const Action& a : la) policyTarget[a.getIndex()] = static_cast<float>(prior);
+        dto.policyTargets.push_back(policyTarget);
+        if (p.replay && game->originalGameDTO) {
+            // a = rootValuesFromInitialInference.size() - 1 is -1 here (nothing was appended): Java's List.get(-1) throws
+            throw MuZeroException("fastRulesLearning cannot replay: no initial inference is recorded");
+        }
+        if (!p.replay) dto.playoutPolicy.push_back(policyTarget);
+        // Node.getRandomAction: nextInt(0, children.size() - 1) - the last child is never drawn (kept as in the reference)
+        result.push_back(la[rng.nextInt(0, static_cast<int>(la.size()) - 1)]);
+    }
+    return result;
+}
+
+// justInitialInferencePolicy (PlanAction.playAfterJustWithInitialInference, PlanAction.java:174-193): the root is expanded
+// from the initial inference, the move is drawn from the renormalised priors, the priors are the policy target.
+std::vector<Action> PlanAction::planActionsJustInitialInference(const std::vector<Game*>& games, const PlayParameters&) {
+    const MuZeroConfig& config = modelService.getConfig();
+    const int A = config.actionSpaceSize;
+    std::vector<const Game*> cg(games.begin(), games.end());
+    modelService.startScope();   // the hidden states are not kept: reuse the pool from its start
+    const std::vector<NetworkIO> io = modelService.initialInference(cg);
+    std::vector<Action> result;
+    for (size_t g = 0; g < games.size(); g++) {
+        Game& game = *games[g];
+        GameDTO& dto = game.getGameDTO();
+        const std::vector<Action> la = game.legalActions();
+        if (la.empty()) throw MuZeroException("planAction on a game without legal actions");
+        // storeEntropyInfo (PlanAction.java:195-202): entropy over the full policy, plain fold
+        dto.legalActionMaxEntropies.push_back(static_cast<float>(std::log(static_cast<double>(la.size()))));
+        double ent = 0.0;
+        for (float pf : io[g].policyValues) {
+            const double pv = pf;
+            ent += (pv == 0 || pv == 1) ? 0.0 : -pv * std::log(pv);
+        }
+        dto.entropies.push_back(static_cast<float>(ent));
+        // Node.expandRootNode -> renormPrior (Node.java:252-269,295-304): HashMap order, Kahan sum
+        std::vector<int> keys;
+        for (const Action& a : la) keys.push_back(a.getIndex());
+        const std::vector<int> order = javaHashMapOrder(keys);
+        std::vector<double> pv;
+        for (int idx : order) pv.push_back(static_cast<double>(io[g].policyValues[idx]));
+        const double sum = javaDoubleStreamSum(pv);
+        std::vector<float> policyTarget(A, 0.f);
+        std::vector<double> prior(order.size());
+        for (size_t i = 0; i < order.size(); i++) {
+            prior[i] = pv[i] / sum;
+            policyTarget[order[i]] = static_cast<float>(prior[i]);
+        }
+        // Functions.selectActionByDrawingFromDistribution: commons-math EnumeratedDistribution normalises the weights and
+        // walks the cumulative sums in list order (= child order); the uniform draw is this class's Rng
+        double total = 0.0;
+        for (double x : prior) total += x;
+        const double u = rng.nextDouble();
+        double cum = 0.0;
+        int pick = order.back();
+        for (size_t i = 0; i < order.size(); i++) {
+            cum += prior[i] / total;
+            if (u < cum) {
+                pick = order[i];
+                break;
+            }
+        }
+        // storeSearchStatistics(justPriorValues = true): a fresh root has improvedValue = vmix = 0
+        dto.rootValueTargets.push_back(0.f);
+        dto.vMix.push_back(0.f);
+        dto.rootEntropyValueTargets.push_back(0.f);
+        dto.policyTargets.push_back(policyTarget);
+        result.push_back(config.newAction(pick));
+    }
+    return result;
+}
+
+// PlanAction.justReplayActionWithInitialInference (PlanAction.java:34-65), for all games at once
+void PlanAction::justReplayActionsWithInitialInference(const std::vector<Game*>& games) {
+    if (games.empty()) return;
+    std::vector<const Game*> cg(games.begin(), games.end());
+    modelService.startScope();
+    const std::vector<NetworkIO> io = modelService.initialInference(cg);
+    for (size_t g = 0; g < games.size(); g++) {
+        Game& game = *games[g];
+        GameDTO& dto = game.getGameDTO();
+        if (!game.originalGameDTO) throw MuZeroException("replay without an original game");
+        dto.rootValuesFromInitialInference.push_back(static_cast<float>(io[g].value));
+        dto.rootEntropyValuesFromInitialInference.push_back(0.f);   // the entropy value head does not exist (always 0)
+        const size_t nActionsReplayed = dto.actions.size();
+        if (nActionsReplayed < game.originalGameDTO->actions.size()) {
+            dto.actions.push_back(game.originalGameDTO->actions[nActionsReplayed]);
+            dto.observations.push_back(game.originalGameDTO->observations.at(1 + nActionsReplayed));
+        }
+    }
 }
 
 // ---- PlayService (P/agent/a_loopcontrol/parallelEpisodes/PlayService.java:39-146) + SelfPlayGame.play --------------
@@ -598,14 +777,53 @@ void PlayService::playGames(const std::vector<Game*>& games, PlayParameters p) {
         for (Game* g : live)
             if ((!p.untilEnd && count == 1) || (p.untilEnd && !g->isDone(replay))) todo.push_back(g);
         if (todo.empty()) break;
-        const std::vector<Action> actions = planAction.planActions(todo, p);
-        for (size_t i = 0; i < todo.size(); i++) {
-            if (p.replay) todo[i]->pseudoApplyFromOriginalGame(actions[i]);
-            else todo[i]->apply(actions[i]);
+        if (p.justReplayWithInitialReference) {
+            planAction.justReplayActionsWithInitialInference(todo);
+        } else {
+            const std::vector<Action> actions = planAction.planActions(todo, p);
+            for (size_t i = 0; i < todo.size(); i++) {
+                if (p.replay) todo[i]->pseudoApplyFromOriginalGame(actions[i]);
+                else todo[i]->apply(actions[i]);
+            }
         }
         live.swap(todo);
     }
+    if (p.justReplayWithInitialReference) planAction.justReplayActionsWithInitialInference(games);   // SelfPlayGame.java:62-64
     modelService.endScope();
+}
+
+void PlayService::reanalyseGames(const std::vector<Game*>& games, PlayParameters p) {
+    // PlayService.java:53-76: keep the original episode aside, clear what the search rewrites, replay it move by move
+    for (Game* game : games) {
+        GameDTO& dto = game->getGameDTO();
+        dto.tdSteps = modelService.getConfig().tdSteps;
+        game->setOriginalGameDTO(dto);
+        const GameDTO& orig = *game->originalGameDTO;
+        dto.policyTargets.clear();
+        dto.rootValueTargets.clear();
+        dto.vMix.clear();
+        dto.rootEntropyValueTargets.clear();
+        dto.entropies.clear();
+        dto.legalActionMaxEntropies.clear();
+        dto.rootValuesFromInitialInference.clear();
+        dto.rootEntropyValuesFromInitialInference.clear();
+        dto.actions.clear();
+        dto.rewards.clear();
+        dto.observations.clear();
+        dto.legalActions.clear();
+        dto.observations.push_back(orig.observations.at(0));
+        dto.legalActions.push_back(orig.legalActions.at(0));
+    }
+    p.replay = true;
+    playGames(games, p);
+}
+
+void PlayService::justReplayGamesWithInitialInference(const std::vector<Game*>& games) {
+    PlayParameters p;
+    p.render = false;
+    p.fastRulesLearning = false;
+    p.justReplayWithInitialReference = true;
+    playGames(games, p);
 }
 
 }  // namespace muzero

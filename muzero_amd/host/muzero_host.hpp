@@ -168,6 +168,7 @@ public:
 
     GameDTO gameDTO;
     std::unique_ptr<GameDTO> originalGameDTO;  // replay / reanalyse (Game.java:67,456-472)
+    void setOriginalGameDTO(const GameDTO& dto) { originalGameDTO.reset(new GameDTO(dto)); }
     bool actionApplied = false;
 
 protected:
@@ -212,6 +213,12 @@ public:
 // ::go(size) carry their network and search parameters so that synthetic positions of those shapes can be
 // searched (tests, bench.py); MuZeroConfig::newGame throws MuZeroException for them.
 
+// Iteration order of a java.util.HashMap<Action, ...> filled in the given order (Action.hashCode() = 59 + index),
+// and DoubleStream.sum() (Kahan): what Node.expandRootNode / renormPrior (Node.java:252-307) rely on, needed here
+// for the justInitialInferencePolicy branch, which normalises the root priors on the host.
+std::vector<int> javaHashMapOrder(const std::vector<int>& keysInInsertionOrder);
+double javaDoubleStreamSum(const std::vector<double>& values);
+
 // ---- random sources --------------------------------------------------------------------------
 // Stand-in for ThreadLocalRandom / SSJ DirichletGen (GumbelFunctions.java:48-54, Functions.java:28-37,
 // 128-138): noise is an INPUT of the device path, so only its distribution matters.  SplitMix64 so
@@ -240,6 +247,8 @@ struct NetworkIO {
 class ModelService {
 public:
     ModelService(const MuZeroConfig& config, int maxGames, int precision, int device, int poolSlots = 0);
+    // without a device context: enough for fastRulesLearning play, which never asks the network (PlanAction.java:81-84)
+    explicit ModelService(const MuZeroConfig& config);
     ~ModelService();
     ModelService(const ModelService&) = delete;
     ModelService& operator=(const ModelService&) = delete;
@@ -280,11 +289,17 @@ class PlanAction {
 public:
     PlanAction(ModelService& modelService, uint64_t seed) : modelService(modelService), rng(seed) {}
     // Returns the chosen action per game and appends to each GameDTO what planAction +
-    // storeSearchStatistics + selectAction append.
+    // storeSearchStatistics + selectAction append.  All modes of the reference: the search (default), replay
+    // (reanalyse: the search runs, the original game's action is returned, GumbelSearch.java:365-370),
+    // justInitialInferencePolicy (PlanAction.java:174-193) and fastRulesLearning (no network, uniform priors).
     std::vector<Action> planActions(const std::vector<Game*>& games, const PlayParameters& p);
+    // PlanAction.java:34-65, batched
+    void justReplayActionsWithInitialInference(const std::vector<Game*>& games);
     int64_t simulationsRun = 0;
 
 private:
+    std::vector<Action> planActionsFastRules(const std::vector<Game*>& games, const PlayParameters& p);
+    std::vector<Action> planActionsJustInitialInference(const std::vector<Game*>& games, const PlayParameters& p);
     ModelService& modelService;
     Rng rng;
 };
@@ -295,7 +310,8 @@ public:
     PlayService(ModelService& modelService, uint64_t seed) : modelService(modelService), planAction(modelService, seed), rng(seed ^ 0x9E3779B97F4A7C15ull) {}
     std::vector<std::unique_ptr<Game>> playNewGames(int numGames, PlayParameters p);
     void playGames(const std::vector<Game*>& games, PlayParameters p);
-    // reanalyseGames / justReplayGamesWithInitialInference (PlayService.java:53-85) are SURVEY.md §8f row N4 (next)
+    void reanalyseGames(const std::vector<Game*>& games, PlayParameters p);            // PlayService.java:53-76
+    void justReplayGamesWithInitialInference(const std::vector<Game*>& games);         // :78-85
     void hybridConfiguration(const std::vector<Game*>& games, int gameLength);         // :92-103
     int maxGameLength = 0;  // gameBuffer.getMaxGameLength()
     int64_t simulationsRun() const { return planAction.simulationsRun; }

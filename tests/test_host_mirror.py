@@ -31,12 +31,12 @@ def test_host_rules_match_reference_plugin_tests():
     assert "ok" in out.stdout
 
 
-def _play(tmp_path, n, play_type, precision, seed=1):
+def _play(tmp_path, n, play_type, precision, seed=1, mode="play"):
     spec = netspec.spec_tictactoe()
     blob = netspec.pack_blob(spec, netspec.random_weights(spec, seed=1))
     wfile = tmp_path / "ttt.f32"
     blob.astype(np.float32).tofile(wfile)
-    out = subprocess.run([_binary("selfplay_main"), str(wfile), str(n), str(seed), play_type, precision],
+    out = subprocess.run([_binary("selfplay_main"), str(wfile), str(n), str(seed), play_type, precision, mode],
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     return json.loads(out.stdout.strip().splitlines()[-1])
@@ -55,3 +55,38 @@ def test_play_new_games_to_the_end(tmp_path, play_type, precision, n):
     assert r["wins_a"] + r["wins_b"] + r["draws"] == n
     # 20 simulations per searched move; moves with one legal action take the shortcut (PlanAction.java:99-101)
     assert r["simulations"] == 20 * (r["moves"] - r["one_option_moves"])
+
+
+@pytest.mark.gpu
+def test_reanalyse_replays_the_original_moves(tmp_path):
+    """PlayService.reanalyseGames (PlayService.java:53-76): the search runs again on every position of a finished
+    episode, the original moves are kept (GumbelSearch.java:365-370), no playout policy is added, and the values of the
+    initial inference repeat exactly (same weights, same positions)."""
+    n = 128
+    r = _play(tmp_path, n, "HYBRID", "fp32", mode="reanalyse")
+    assert r["games"] == n and r["not_done"] == 0 and r["illegal_actions"] == 0
+    assert r["replay_action_mismatch"] == 0
+    assert r["replay_length_mismatch"] == 0
+    assert r["replay_playout_grew"] == 0
+    assert r["replay_values_equal"] == n
+    assert r["replay_targets_equal"] < n          # fresh Gumbel / Dirichlet noise: the policy targets are new
+    assert r["simulations"] == 2 * 20 * (r["moves"] - r["one_option_moves"])
+
+
+@pytest.mark.gpu
+def test_just_replay_with_initial_inference(tmp_path):
+    """PlayService.justReplayGamesWithInitialInference (PlayService.java:78-85, PlanAction.java:34-65)."""
+    n = 64
+    r = _play(tmp_path, n, "PLAYOUT", "fp32", mode="justreplay")
+    assert r["replay_action_mismatch"] == 0 and r["replay_length_mismatch"] == 0
+    assert r["replay_values_equal"] == n
+
+
+@pytest.mark.gpu
+def test_just_initial_inference_policy(tmp_path):
+    """PlanAction.playAfterJustWithInitialInference (PlanAction.java:174-193): moves drawn from the renormalised priors."""
+    n = 256
+    r = _play(tmp_path, n, "PLAYOUT", "bf16", mode="initial")
+    assert r["games"] == n and r["not_done"] == 0 and r["illegal_actions"] == 0
+    assert r["bad_lengths"] == 0 and r["bad_policy_targets"] == 0
+    assert r["simulations"] == 0
