@@ -75,6 +75,14 @@ struct GameDTO {
     bool hybrid = false;
     long tHybrid = -1;
     int tdSteps = 0;
+    // bookkeeping fields of the replay buffer that travel in GameProto (GameDTO.java:79-100)
+    std::string networkName = "NONE";
+    float lastValueError = 0.f;
+    long count = 0, nextSurpriseCheck = 0;
+    bool surprised = false;
+    int trainingEpoch = 0;
+    float pRandomActionRawSum = 0.f;
+    int pRandomActionRawCount = 0;
 };
 
 enum class PlayTypeKey { PLAYOUT, HYBRID, REANALYSE };
