@@ -859,6 +859,17 @@ int mz_read_hidden(mz_ctx* ctx, int32_t slot, float* out) {
     const size_t n = (size_t)ctx->nd.C * ctx->nd.HW;
     const long long base = (long long)ctx->cfg.max_games * ctx->N;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->cfg.precision == MZ_PRECISION_BF16) {
+        // the MFMA path keeps a slot as [C/4][HW][4] (channel quads interleaved, net_mfma.hip x_load / x_store);
+        // the caller gets the reference's [C][H][W]
+        const int HW = ctx->nd.HW;
+        std::vector<float> q(n), r(n);
+        HIP_TRY(hipMemcpy(q.data(), ctx->pool + (size_t)(base + slot) * n, n * sizeof(float), hipMemcpyDefault));
+        for (int ch = 0; ch < ctx->nd.C; ch++)
+            for (int p = 0; p < HW; p++) r[(size_t)ch * HW + p] = q[((size_t)(ch / 4) * HW + p) * 4 + ch % 4];
+        HIP_TRY(hipMemcpy(out, r.data(), n * sizeof(float), hipMemcpyDefault));
+        return 0;
+    }
     HIP_TRY(hipMemcpy(out, ctx->pool + (size_t)(base + slot) * n, n * sizeof(float), hipMemcpyDefault));
     return 0;
 }

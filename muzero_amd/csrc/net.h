@@ -34,7 +34,8 @@ struct NetProgramF32 {
     int c_pad, cb_pad;  // channel counts rounded up to a multiple of 4
 };
 
-// Batch I/O of one inference launch.  Hidden states are [slot][C][HW] fp32 in `pool`.
+// Batch I/O of one inference launch.  Hidden states are fp32 slots of C*HW floats in `pool`: [C][HW] on the fp32 path,
+// [C/4][HW][4] (channel quads interleaved) on the MFMA path; mz_read_hidden always returns [C][H][W].
 struct NetIO {
     const float* obs;         // initial: [B][O][HW]
     const int* src_slot;      // recurrent: [B] (global slot)

@@ -570,35 +570,40 @@ __device__ __forceinline__ void ctx_init(Ctx& c, char* smem, const LdsPlan& L, c
 #endif
 }
 
-// X <-> [slot][C][HW] fp32 in the hidden-state pool (slot index from meta row `which`); this wave's row tiles.
+// X <-> the hidden-state pool (slot index from meta row `which`); this wave's row tiles.  On this path a slot is
+// laid out [C/4][HW][4] fp32 (channel quads interleaved): a lane's four consecutive accumulator registers (channels
+// 32rt + 8qd + 4h + 0..3 of its cell) are one 16-byte access and a wave's accesses are contiguous 512-byte runs -
+// 16 instead of 64 memory instructions per lane.  mz_read_hidden un-permutes (api.cpp).
 template <int NR>
 __device__ __forceinline__ void x_load(Ctx& c, const Col& k, const float* pool, int which, int C, f32x16 (&X)[NR]) {
     // unconditional loads (dead columns read slot meta[..][0], which is always a valid slot) + select:
     // a per-load branch would serialise dependent round trips
     const int bd = k.valid ? k.board : 0;
-    const float* src = pool + (long long)c.meta[which * MAXNB + bd] * C * c.HW + k.p;
+    const float* src = pool + (long long)c.meta[which * MAXNB + bd] * C * c.HW + (k.p + c.h * c.HW) * 4;
     int hw = c.HW;
-    asm volatile("" : "+s"(hw));   // opaque per call: keeps the compiler from holding (and spilling) 64 row offsets
+    asm volatile("" : "+s"(hw));   // opaque per call: keeps the compiler from holding (and spilling) the row offsets
     const bool keep = k.live;
 #pragma unroll
     for (int rt = 0; rt < NR; rt++)
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const int ch = 32 * (c.wr * NR + rt) + (i & 3) + 8 * (i >> 2) + 4 * c.h;
-            const float v = src[ch * hw];
-            X[rt][i] = keep ? v : 0.f;  // select, not multiply: dead slots may hold NaN bit patterns
+        for (int qd = 0; qd < 4; qd++) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + (8 * (c.wr * NR + rt) + 2 * qd) * hw * 4);
+#pragma unroll
+            for (int e = 0; e < 4; e++) X[rt][4 * qd + e] = keep ? v[e] : 0.f;  // select: dead slots may hold NaN bit patterns
         }
 }
 template <int NR>
 __device__ __forceinline__ void x_store(Ctx& c, const Col& k, float* pool, int C, const f32x16 (&X)[NR]) {
     if (!k.live) return;
-    float* dst = pool + (long long)c.meta[MAXNB + k.board] * C * c.HW + k.p;
+    float* dst = pool + (long long)c.meta[MAXNB + k.board] * C * c.HW + (k.p + c.h * c.HW) * 4;
     int hw = c.HW;
     asm volatile("" : "+s"(hw));
 #pragma unroll
     for (int rt = 0; rt < NR; rt++)
 #pragma unroll
-        for (int i = 0; i < 16; i++) dst[(32 * (c.wr * NR + rt) + (i & 3) + 8 * (i >> 2) + 4 * c.h) * hw] = X[rt][i];
+        for (int qd = 0; qd < 4; qd++)
+            *reinterpret_cast<f32x4*>(dst + (8 * (c.wr * NR + rt) + 2 * qd) * hw * 4) =
+                (f32x4){X[rt][4 * qd], X[rt][4 * qd + 1], X[rt][4 * qd + 2], X[rt][4 * qd + 3]};
 }
 
 // ---- [conv0] + bottleneck blocks b0..b1-1 + [rescale, heads] -----------------------------------
@@ -766,19 +771,24 @@ __global__ __launch_bounds__(HT) void k_heads(NetDims d, HeadDev hd, NetIO io) {
         float a00 = 0.f, a01 = 0.f, a02 = 0.f, a10 = 0.f, a11 = 0.f, a12 = 0.f;
         const bool v0 = lane < HW, v1 = lane + 64 < HW;
         if (live) {
-            const float* h = io.pool + (long long)io.dst_slot[g] * C * HW;
-            const float* h0 = h + (v0 ? lane : 0);
-            const float* h1 = h + (v1 ? lane + 64 : 0);
-#pragma unroll 16
-            for (int ch = 0; ch < C; ch++) {
-                const float x0 = h0[ch * HW], x1 = h1[ch * HW];
-                const float w0 = hd.hconv[ch], w1 = hd.hconv[C + ch], w2 = hd.hconv[2 * C + ch];
-                a00 = fmaf(x0, w0, a00);
-                a01 = fmaf(x0, w1, a01);
-                a02 = fmaf(x0, w2, a02);
-                a10 = fmaf(x1, w0, a10);
-                a11 = fmaf(x1, w1, a11);
-                a12 = fmaf(x1, w2, a12);
+            const float* h = io.pool + (long long)io.dst_slot[g] * C * HW;   // [C/4][HW][4]
+            const float* h0 = h + (v0 ? lane : 0) * 4;
+            const float* h1 = h + (v1 ? lane + 64 : 0) * 4;
+#pragma unroll 8
+            for (int cq = 0; cq < C / 4; cq++) {
+                const f32x4 x0 = *reinterpret_cast<const f32x4*>(h0 + cq * HW * 4);
+                const f32x4 x1 = *reinterpret_cast<const f32x4*>(h1 + cq * HW * 4);
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int ch = 4 * cq + e;
+                    const float w0 = hd.hconv[ch], w1 = hd.hconv[C + ch], w2 = hd.hconv[2 * C + ch];
+                    a00 = fmaf(x0[e], w0, a00);
+                    a01 = fmaf(x0[e], w1, a01);
+                    a02 = fmaf(x0[e], w2, a02);
+                    a10 = fmaf(x1[e], w0, a10);
+                    a11 = fmaf(x1[e], w1, a11);
+                    a12 = fmaf(x1[e], w2, a12);
+                }
             }
         }
         // LayerNorm over (2, HW) for the policy features and over (1, HW) for the value features
