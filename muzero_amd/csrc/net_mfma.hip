@@ -210,6 +210,7 @@ struct WRing {
         gptr += (size_t)nf * 1024;
         ld_idx = ld_idx == NSLOT - 1 ? 0 : ld_idx + 1;
     }
+    __device__ __forceinline__ const char* peek() const { return lds + rd_idx * (SM * 1024); }   // the next acquire()'s slot
     __device__ __forceinline__ const char* acquire() {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         const char* p = lds + rd_idx * (SM * 1024);
@@ -412,8 +413,10 @@ __device__ __forceinline__ void conv_lds(Ctx& c, const Col& k, WRing<G::NW, G::S
     const char* img = c.smem + c.L.img_off;
     const char* zrow = c.smem + c.L.zrow_off;
     const char* slot = nullptr;
-    // operands of k-step kk: B from the image (own column, or the tap's neighbour row), A from the ring slot
-    auto load_ops = [&](int kk, bf16x8& b, bf16x8(&a)[NROW]) {
+    int cur_stage = 0;
+    const int frag0 = (c.wr * NROW) * 1024 + c.lane * 16;
+    // operands of k-step kk: B from the image (own column, or the tap's neighbour row), A from ring slot sl
+    auto load_ops = [&](int kk, const char* sl, bf16x8& b, bf16x8(&a)[NROW]) {
         const int t = kk / KS, ks = kk % KS;
         const char* row;
         if (TAPS == 9) {
@@ -424,35 +427,49 @@ __device__ __forceinline__ void conv_lds(Ctx& c, const Col& k, WRing<G::NW, G::S
         }
         b = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(row + (16 * ks + 8 * c.h) * 2));
 #pragma unroll
-        for (int ro = 0; ro < NROW; ro++)
-            a[ro] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(slot + ((kk % SK) * NROT + ro) * 1024));
+        for (int ro = 0; ro < NROW; ro++) {
+#if defined(MZ_EXP_A1)   // timing experiment only (wrong results): one A read per k-step
+            if (ro > 0) { a[ro] = a[0]; continue; }
+#endif
+            a[ro] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(sl + ((kk % SK) * NROT + ro) * 1024));
+        }
     };
-    // Software pipeline: the operands of k-step kk+1 are requested before the MFMAs of kk issue (inside a stage;
-    // a new stage starts with its barrier), so LDS latency hides behind the matrix pipe instead of in front of it.
-    // (Two and three k-steps ahead measured no better; explicit registers, not arrays: indexing by kk % n bloated
-    // the code badly for some n.)
-    bf16x8 bcur, bnxt, acur[NROW], anxt[NROW];
-#pragma unroll
-    for (int kk = 0; kk < KK; kk++) {
+    // Software pipeline: the operands of k-step kk+2 are requested before the MFMAs of kk issue, so LDS latency
+    // (a couple of hundred cycles with the array three quarters busy) hides behind the matrix pipe instead of in
+    // front of it.  This runs across the stage boundaries inside the conv too: acquire() waits for all of this
+    // wave's DMA, so the barrier of stage s has already published stage s+1, and its first operands may be read
+    // before the barrier of s+1 (which then only frees slot s).  Three explicit operand sets, rotated by unrolling
+    // the k loop by three (indexing register arrays by kk % n bloated the code badly).
+    static_assert(SK >= 2 || NST == 1, "the two-step look-ahead reaches at most into the next stage");
+    bf16x8 b0, b1, b2, a0[NROW], a1[NROW], a2[NROW];
+    auto fetch = [&](int kk, bf16x8& b, bf16x8(&a)[NROW]) {
+        if (kk < KK) load_ops(kk, kk / SK == cur_stage ? slot : ring.peek() + frag0, b, a);
+    };
+    auto step = [&](int kk, bf16x8& b, bf16x8(&a)[NROW], bf16x8& bp, bf16x8(&ap)[NROW]) {
+        if (kk >= KK) return;
         if (kk % SK == 0) {
             STAMP(c, kk == 0 ? ST_OTHER : ST_MMA);
-            slot = ring.acquire() + (c.wr * NROW) * 1024 + c.lane * 16;
+            slot = ring.acquire() + frag0;
+            cur_stage = kk / SK;
             STAMP(c, ST_ACQ);
             const int j = kk / SK + 2;   // the stage requested now
             ring.issue(j < NST ? stage_frags(KK, NROT, G::SM, j) : (j == NST ? after1 : after2));
-            load_ops(kk, bcur, acur);
+            if (kk == 0) {
+                fetch(0, b0, a0);
+                fetch(1, b1, a1);
+            }
         }
-        const bool more = kk + 1 < KK && (kk + 1) % SK != 0;
-        if (more) load_ops(kk + 1, bnxt, anxt);
+        fetch(kk + 2, bp, ap);
         __builtin_amdgcn_sched_barrier(0);   // the scheduler would otherwise sink these reads below the MFMAs
 #pragma unroll
-        for (int ro = 0; ro < NROW; ro++) acc[ro] = MFMA(acur[ro], bcur, acc[ro]);
+        for (int ro = 0; ro < NROW; ro++) acc[ro] = MFMA(a[ro], b, acc[ro]);
         __builtin_amdgcn_sched_barrier(0);
-        if (more) {
-            bcur = bnxt;
+    };
 #pragma unroll
-            for (int ro = 0; ro < NROW; ro++) acur[ro] = anxt[ro];
-        }
+    for (int kk = 0; kk < KK; kk += 3) {
+        step(kk, b0, a0, b2, a2);
+        step(kk + 1, b1, a1, b0, a0);
+        step(kk + 2, b2, a2, b1, a1);
     }
     STAMP(c, ST_MMA);
 }
