@@ -103,13 +103,13 @@ struct LdsPlan {
     int kp, qt;
 };
 
-// Workgroup geometry: NW waves as a WR x WC grid, ring slots of SM fragments (KiB), WPE = waves per SIMD the
-// register budget is cut for (2 workgroups of 6 waves per CU = 3 per SIMD, ...).
-template <int C_, int CB_, int WR_, int NW_, int SM_, int WPE_>
+// Workgroup geometry: NW waves as a WR x WC grid, each wave owning NC column tiles of 32 columns; ring slots of SM
+// fragments (KiB); WPE = waves per SIMD the register budget is cut for.
+template <int C_, int CB_, int WR_, int NW_, int SM_, int WPE_, int NC_ = 1>
 struct Geo {
-    static constexpr int C = C_, CB = CB_, WR = WR_, NW = NW_, SM = SM_, WPE = WPE_;
+    static constexpr int C = C_, CB = CB_, WR = WR_, NW = NW_, SM = SM_, WPE = WPE_, NC = NC_;
     static constexpr int NT = 64 * NW;
-    static constexpr int WC = NW / WR, COLS = 32 * WC;
+    static constexpr int WC = NW / WR, COLS = 32 * WC * NC;
     static_assert(NW % WR == 0 && NW % 2 == 0, "wave grid");
     static constexpr int NRC = C / 32, NRB = CB / 32;       // row tiles of the whole layer
     static constexpr int NRCW = NRC / WR, NRBW = NRB / WR;  // row tiles one wave owns
@@ -210,7 +210,6 @@ struct WRing {
         gptr += (size_t)nf * 1024;
         ld_idx = ld_idx == NSLOT - 1 ? 0 : ld_idx + 1;
     }
-    __device__ __forceinline__ const char* peek() const { return lds + rd_idx * (SM * 1024); }   // the next acquire()'s slot
     __device__ __forceinline__ const char* acquire() {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         const char* p = lds + rd_idx * (SM * 1024);
@@ -246,16 +245,26 @@ __device__ __forceinline__ float wave_red(float v) {
 // value; (2) lanes < NB publish wpart[parity][board][wave] (neutral where the wave holds none of the
 // board), barrier, and every lane combines the eight wave partials of its own board.  wpart alternates
 // between two buffers so the next reduction's writes cannot overtake this one's reads.
-template <int MODE, int NW>
-__device__ __forceinline__ void board_reduce(Ctx& c, const Col& k, float& a, float& b, float n_inv) {
+template <int MODE, int NW, int NC>
+__device__ __forceinline__ void board_reduce(Ctx& c, const Col (&k)[NC], float (&a)[NC], float (&b)[NC], float n_inv) {
     const float na = MODE == 0 ? 0.f : INFINITY, nb = MODE == 0 ? 0.f : -INFINITY;
-    const int bmin = (32 * c.wc) / c.HW;
-    int bmax = (32 * c.wc + 31) / c.HW;
+    const int bmin = (32 * NC * c.wc) / c.HW;
+    int bmax = (32 * NC * c.wc + 32 * NC - 1) / c.HW;
     if (bmax > c.NB - 1) bmax = c.NB - 1;
     float ma = na, mb = nb;
     for (int bd = bmin; bd <= bmax; bd++) {
-        const bool in = k.board == bd;
-        float x = in ? a : na, y = in ? b : nb;
+        float x = na, y = nb;
+#pragma unroll
+        for (int ct = 0; ct < NC; ct++) {
+            const bool in = k[ct].board == bd;
+            if (MODE == 0) {
+                x += in ? a[ct] : 0.f;
+                y += in ? b[ct] : 0.f;
+            } else {
+                x = fminf(x, in ? a[ct] : na);
+                y = fmaxf(y, in ? b[ct] : nb);
+            }
+        }
         if (MODE == 0) {
             x = wave_red<0>(x);
             y = wave_red<0>(y);
@@ -272,46 +281,53 @@ __device__ __forceinline__ void board_reduce(Ctx& c, const Col& k, float& a, flo
     c.parity ^= 1;
     if (c.lane < c.NB) *reinterpret_cast<f32x2*>(wp + (c.lane * NW + c.wave) * 2) = (f32x2){ma, mb};
     lds_barrier();
-    const int bd = k.board < MAXNB ? k.board : 0;
-    float x = na, y = nb;
 #pragma unroll
-    for (int w4 = 0; w4 < NW / 2; w4++) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(wp + (bd * NW + 2 * w4) * 2);
-        const float u0 = t[0], v0 = t[1], u1 = t[2], v1 = t[3];
-        if (MODE == 0) {
-            x += u0 + u1;
-            y += v0 + v1;
-        } else {
-            x = fminf(x, fminf(u0, u1));
-            y = fmaxf(y, fmaxf(v0, v1));
+    for (int ct = 0; ct < NC; ct++) {
+        const int bd = k[ct].board < MAXNB ? k[ct].board : 0;
+        float x = na, y = nb;
+#pragma unroll
+        for (int w4 = 0; w4 < NW / 2; w4++) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(wp + (bd * NW + 2 * w4) * 2);
+            const float u0 = t[0], v0 = t[1], u1 = t[2], v1 = t[3];
+            if (MODE == 0) {
+                x += u0 + u1;
+                y += v0 + v1;
+            } else {
+                x = fminf(x, fminf(u0, u1));
+                y = fmaxf(y, fmaxf(v0, v1));
+            }
         }
-    }
-    if (MODE == 0) {
-        const float mean = x * n_inv;
-        const float var = fmaxf(y * n_inv - mean * mean, 0.f);
-        a = k.valid ? mean : 0.f;
-        b = k.valid ? __builtin_amdgcn_rsqf(var + 1e-5f) : 0.f;   // padded columns: neutral statistics
-    } else {
-        a = k.valid ? x : 0.f;
-        b = k.valid ? y : 1.f;
+        if (MODE == 0) {
+            const float mean = x * n_inv;
+            const float var = fmaxf(y * n_inv - mean * mean, 0.f);
+            a[ct] = k[ct].valid ? mean : 0.f;
+            b[ct] = k[ct].valid ? __builtin_amdgcn_rsqf(var + 1e-5f) : 0.f;   // padded columns: neutral statistics
+        } else {
+            a[ct] = k[ct].valid ? x : 0.f;
+            b[ct] = k[ct].valid ? y : 1.f;
+        }
     }
 }
 
 // LayerNorm statistics of this wave's NR row tiles x own column -> per-column (mean, rstd) of the board.
-template <int NR, int NW>
-__device__ __forceinline__ void ln_stats(Ctx& c, const Col& k, const f32x16 (&v)[NR], int nch, float& mean, float& rstd) {
-    f32x2 s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
+template <int NR, int NW, int NC>
+__device__ __forceinline__ void ln_stats(Ctx& c, const Col (&k)[NC], const f32x16 (&v)[NR][NC], int nch, float (&mean)[NC],
+                                         float (&rstd)[NC]) {
 #pragma unroll
-    for (int rt = 0; rt < NR; rt++)
+    for (int ct = 0; ct < NC; ct++) {
+        f32x2 s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 16; i += 2) {
-            f32x2 x = {v[rt][i], v[rt][i + 1]};
-            s2 += x;
-            q2 = x * x + q2;
-        }
-    mean = k.valid ? s2.x + s2.y : 0.f;
-    rstd = k.valid ? q2.x + q2.y : 0.f;
-    board_reduce<0, NW>(c, k, mean, rstd, 1.0f / (float)(nch * c.HW));
+        for (int rt = 0; rt < NR; rt++)
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) {
+                f32x2 x = {v[rt][ct][i], v[rt][ct][i + 1]};
+                s2 += x;
+                q2 = x * x + q2;
+            }
+        mean[ct] = k[ct].valid ? s2.x + s2.y : 0.f;
+        rstd[ct] = k[ct].valid ? q2.x + q2.y : 0.f;
+    }
+    board_reduce<0, NW, NC>(c, k, mean, rstd, 1.0f / (float)(nch * c.HW));
 }
 
 // gamma/beta of global row tile rt for this lane's (cell, channels): 4 x 16-byte loads.
@@ -376,110 +392,108 @@ __device__ __forceinline__ void img_store(char* img, int rs, int col, int rt, in
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
-// relu(LN(v)) of this wave's NR row tiles -> image rows of its own column.  gb = this LayerNorm's table.
-template <int NR, int NW>
-__device__ __forceinline__ void ln_to_image(Ctx& c, const Col& k, const u32x4* gb, const f32x16 (&v)[NR], int nch,
+// relu(LN(v)) of this wave's NR row tiles -> image rows of its own columns.  gb = this LayerNorm's table.
+template <int NR, int NW, int NC>
+__device__ __forceinline__ void ln_to_image(Ctx& c, const Col (&k)[NC], const u32x4* gb, const f32x16 (&v)[NR][NC], int nch,
                                             int rs) {
     char* img = c.smem + c.L.img_off;
-    u32x4 g[NR][4];
+    u32x4 g[NR][NC][4];
     // the first two row tiles are requested before the statistics round trip, the rest right after it
-    gb_load(gb, c, k, c.wr * NR, g[0]);
-    if (NR > 1) gb_load(gb, c, k, c.wr * NR + 1, g[1]);
-    float mean, rstd;
+#pragma unroll
+    for (int rt = 0; rt < (NR < 2 ? NR : 2); rt++)
+#pragma unroll
+        for (int ct = 0; ct < NC; ct++) gb_load(gb, c, k[ct], c.wr * NR + rt, g[rt][ct]);
+    float mean[NC], rstd[NC];
     STAMP(c, ST_OTHER);
-    ln_stats<NR, NW>(c, k, v, nch, mean, rstd);
+    ln_stats<NR, NW, NC>(c, k, v, nch, mean, rstd);
     STAMP(c, ST_STATS);
 #pragma unroll
-    for (int rt = 2; rt < NR; rt++) gb_load(gb, c, k, c.wr * NR + rt, g[rt]);
-    const float nmr = -mean * rstd;
+    for (int rt = 2; rt < NR; rt++)
 #pragma unroll
-    for (int rt = 0; rt < NR; rt++) {
-        unsigned o[8];
-        ln_apply_pk(v[rt], rstd, nmr, g[rt], o);   // padded columns: gamma = beta = 0 -> zeros
-        img_store_pk(img, rs, k.col, c.wr * NR + rt, c.h, o);
-    }
+        for (int ct = 0; ct < NC; ct++) gb_load(gb, c, k[ct], c.wr * NR + rt, g[rt][ct]);
+#pragma unroll
+    for (int rt = 0; rt < NR; rt++)
+#pragma unroll
+        for (int ct = 0; ct < NC; ct++) {
+            unsigned o[8];
+            ln_apply_pk(v[rt][ct], rstd[ct], -mean[ct] * rstd[ct], g[rt][ct], o);   // padded columns: gamma = beta = 0 -> zeros
+            img_store_pk(img, rs, k[ct].col, c.wr * NR + rt, c.h, o);
+        }
     STAMP(c, ST_NORM);
 }
 
-// acc[ro] += conv(image) for this wave's NROW output row tiles (of NROT in the layer).
+// acc[ro][ct] += conv(image) for this wave's NROW output row tiles (of NROT in the layer) x NC column tiles.
 // Stream order of the layer's fragments: (tap, ks, ro) with natural k.  The first two stages of the stream from
 // here on must already be in flight; after1 / after2 = the two stages that follow this conv's last (0: nothing).
+// LDS reads per MFMA = (NROW + NC) / (NROW * NC): the A fragments are shared by the wave's column tiles.
 template <class G, int KS, int TAPS, int NROT, int NROW, int RS>
-__device__ __forceinline__ void conv_lds(Ctx& c, const Col& k, WRing<G::NW, G::SM>& ring, f32x16 (&acc)[NROW],
-                                         int after1, int after2) {
+__device__ __forceinline__ void conv_lds(Ctx& c, const Col (&k)[G::NC], WRing<G::NW, G::SM>& ring,
+                                         f32x16 (&acc)[NROW][G::NC], int after1, int after2) {
+    constexpr int NC = G::NC;
     constexpr int KK = TAPS * KS;
     constexpr int SK = stage_ksteps(KK, NROT, G::SM);
     constexpr int NST = num_stages(KK, NROT, G::SM);
     const char* img = c.smem + c.L.img_off;
     const char* zrow = c.smem + c.L.zrow_off;
     const char* slot = nullptr;
-    int cur_stage = 0;
     const int frag0 = (c.wr * NROW) * 1024 + c.lane * 16;
-    // operands of k-step kk: B from the image (own column, or the tap's neighbour row), A from ring slot sl
-    auto load_ops = [&](int kk, const char* sl, bf16x8& b, bf16x8(&a)[NROW]) {
+    struct Ops {
+        bf16x8 b[NC], a[NROW];
+    };
+    // operands of k-step kk: B from the image (own columns, or the tap's neighbour rows), A from ring slot sl
+    auto load_ops = [&](int kk, const char* sl, Ops& o) {
         const int t = kk / KS, ks = kk % KS;
-        const char* row;
-        if (TAPS == 9) {
-            const int d = (t / 3 - 1) * c.Wd + (t % 3 - 1);
-            row = ((k.nbmask >> t) & 1u) ? img + (k.col + d) * RS : zrow;
-        } else {
-            row = img + k.col * RS;
-        }
-        b = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(row + (16 * ks + 8 * c.h) * 2));
 #pragma unroll
-        for (int ro = 0; ro < NROW; ro++) {
-#if defined(MZ_EXP_A1)   // timing experiment only (wrong results): one A read per k-step
-            if (ro > 0) { a[ro] = a[0]; continue; }
-#endif
-            a[ro] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(sl + ((kk % SK) * NROT + ro) * 1024));
+        for (int ct = 0; ct < NC; ct++) {
+            const char* row;
+            if (TAPS == 9) {
+                const int d = (t / 3 - 1) * c.Wd + (t % 3 - 1);
+                row = ((k[ct].nbmask >> t) & 1u) ? img + (k[ct].col + d) * RS : zrow;
+            } else {
+                row = img + k[ct].col * RS;
+            }
+            o.b[ct] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(row + (16 * ks + 8 * c.h) * 2));
         }
+#pragma unroll
+        for (int ro = 0; ro < NROW; ro++)
+            o.a[ro] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(sl + ((kk % SK) * NROT + ro) * 1024));
     };
-    // Software pipeline: the operands of k-step kk+2 are requested before the MFMAs of kk issue, so LDS latency
-    // (a couple of hundred cycles with the array three quarters busy) hides behind the matrix pipe instead of in
-    // front of it.  This runs across the stage boundaries inside the conv too: acquire() waits for all of this
-    // wave's DMA, so the barrier of stage s has already published stage s+1, and its first operands may be read
-    // before the barrier of s+1 (which then only frees slot s).  Three explicit operand sets, rotated by unrolling
-    // the k loop by three (indexing register arrays by kk % n bloated the code badly).
-    static_assert(SK >= 2 || NST == 1, "the two-step look-ahead reaches at most into the next stage");
-    bf16x8 b0, b1, b2, a0[NROW], a1[NROW], a2[NROW];
-    auto fetch = [&](int kk, bf16x8& b, bf16x8(&a)[NROW]) {
-        if (kk < KK) load_ops(kk, kk / SK == cur_stage ? slot : ring.peek() + frag0, b, a);
-    };
-    auto step = [&](int kk, bf16x8& b, bf16x8(&a)[NROW], bf16x8& bp, bf16x8(&ap)[NROW]) {
-        if (kk >= KK) return;
+    // Software pipeline: the operands of k-step kk+1 are requested before the MFMAs of kk issue (inside a stage;
+    // a new stage starts with its barrier), so LDS latency hides behind the matrix pipe instead of in front of it.
+    // Measured no better (k_seg 2 % slower): two k-steps ahead with three operand sets, and running the look-ahead
+    // across the stage barriers - the loops are bound by LDS throughput (1.5 ds_read_b128 per MFMA), not latency.
+    Ops ocur, onxt;
+#pragma unroll
+    for (int kk = 0; kk < KK; kk++) {
         if (kk % SK == 0) {
             STAMP(c, kk == 0 ? ST_OTHER : ST_MMA);
             slot = ring.acquire() + frag0;
-            cur_stage = kk / SK;
             STAMP(c, ST_ACQ);
             const int j = kk / SK + 2;   // the stage requested now
             ring.issue(j < NST ? stage_frags(KK, NROT, G::SM, j) : (j == NST ? after1 : after2));
-            if (kk == 0) {
-                fetch(0, b0, a0);
-                fetch(1, b1, a1);
-            }
+            load_ops(kk, slot, ocur);
         }
-        fetch(kk + 2, bp, ap);
+        const bool more = kk + 1 < KK && (kk + 1) % SK != 0;
+        if (more) load_ops(kk + 1, slot, onxt);
         __builtin_amdgcn_sched_barrier(0);   // the scheduler would otherwise sink these reads below the MFMAs
 #pragma unroll
-        for (int ro = 0; ro < NROW; ro++) acc[ro] = MFMA(a[ro], b, acc[ro]);
-        __builtin_amdgcn_sched_barrier(0);
-    };
+        for (int ro = 0; ro < NROW; ro++)
 #pragma unroll
-    for (int kk = 0; kk < KK; kk += 3) {
-        step(kk, b0, a0, b2, a2);
-        step(kk + 1, b1, a1, b0, a0);
-        step(kk + 2, b2, a2, b1, a1);
+            for (int ct = 0; ct < NC; ct++) acc[ro][ct] = MFMA(ocur.a[ro], ocur.b[ct], acc[ro][ct]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) ocur = onxt;
     }
     STAMP(c, ST_MMA);
 }
 
-template <int NR>
-__device__ __forceinline__ void zero_acc(f32x16 (&a)[NR]) {
+template <int NR, int NC>
+__device__ __forceinline__ void zero_acc(f32x16 (&a)[NR][NC]) {
 #pragma unroll
     for (int r = 0; r < NR; r++)
 #pragma unroll
-        for (int i = 0; i < 16; i++) a[r][i] = 0.f;
+        for (int ct = 0; ct < NC; ct++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) a[r][ct][i] = 0.f;
 }
 
 // BottleneckResidualBlock: x + c4(relu(LN(c3(relu(LN(c2(relu(LN(c1(relu(LN(x))))))))))))
@@ -497,8 +511,8 @@ struct BlockStages {
 
 // On entry the first two stages of the block are in flight; on exit those of the next block (if has_next).
 template <class G>
-__device__ __forceinline__ void bottleneck(Ctx& c, const Col& k, WRing<G::NW, G::SM>& ring, const u32x4* gb, f32x16 (&X)[G::NRCW],
-                                           bool has_next) {
+__device__ __forceinline__ void bottleneck(Ctx& c, const Col (&k)[G::NC], WRing<G::NW, G::SM>& ring, const u32x4* gb,
+                                           f32x16 (&X)[G::NRCW][G::NC], bool has_next) {
     constexpr int C = G::C, CB = G::CB;
     using BS = BlockStages<G>;
     const int nx0 = has_next ? BS::open0 : 0, nx1 = has_next ? BS::open1 : 0;
@@ -509,28 +523,28 @@ __device__ __forceinline__ void bottleneck(Ctx& c, const Col& k, WRing<G::NW, G:
     const u32x4* gb2 = gb1 + G::NRC * 8 * e;
     const u32x4* gb3 = gb2 + G::NRB * 8 * e;
     const u32x4* gb4 = gb3 + G::NRB * 8 * e;
-    f32x16 a1[G::NRBW];
+    f32x16 a1[G::NRBW][G::NC];
 
     // LN1 -> image -> c1 (1x1, C -> CB)
-    ln_to_image<G::NRCW, G::NW>(c, k, gb1, X, C, RSC);
-    zero_acc<G::NRBW>(a1);
+    ln_to_image<G::NRCW, G::NW, G::NC>(c, k, gb1, X, C, RSC);
+    zero_acc(a1);
     conv_lds<G, KSC, 1, G::NRB, G::NRBW, RSC>(c, k, ring, a1, BS::c2(0), BS::c2(1));
     // LN2 -> image -> c2 (3x3), LN3 -> image -> c3 (3x3); the image is consumed before a1 is rewritten
 #pragma unroll
     for (int layer = 0; layer < 2; layer++) {
-        ln_to_image<G::NRBW, G::NW>(c, k, layer == 0 ? gb2 : gb3, a1, CB, RSB);
-        zero_acc<G::NRBW>(a1);
+        ln_to_image<G::NRBW, G::NW, G::NC>(c, k, layer == 0 ? gb2 : gb3, a1, CB, RSB);
+        zero_acc(a1);
         conv_lds<G, KSB, 9, G::NRB, G::NRBW, RSB>(c, k, ring, a1, layer == 0 ? BS::c2(0) : BS::c4(0),
                                                   layer == 0 ? BS::c2(1) : (BS::n4 > 1 ? BS::c4(1) : nx0));
     }
     // LN4 -> image -> c4 (1x1, CB -> C) accumulated into X
-    ln_to_image<G::NRBW, G::NW>(c, k, gb4, a1, CB, RSB);
+    ln_to_image<G::NRBW, G::NW, G::NC>(c, k, gb4, a1, CB, RSB);
     conv_lds<G, KSB, 1, G::NRC, G::NRCW, RSB>(c, k, ring, X, nx0, nx1);
 }
 
 // ---- shared prologue: per-board meta data and per-lane column info -----------------------------
-template <int IN>
-__device__ __forceinline__ bool setup(const NetDims& d, const NetIO& io, int NB, Ctx& c, Col& k) {
+template <int IN, int NC>
+__device__ __forceinline__ bool setup(const NetDims& d, const NetIO& io, int NB, Ctx& c, Col (&kk)[NC]) {
     const int tid = threadIdx.x;
     const int g0 = blockIdx.x * NB;
     if (tid < MAXNB) {
@@ -547,7 +561,10 @@ __device__ __forceinline__ bool setup(const NetDims& d, const NetIO& io, int NB,
     int any = 0;
     for (int b = 0; b < NB; b++) any |= c.meta[2 * MAXNB + b];
     if (!any) return false;
-    const int col = 32 * c.wc + c.r;
+#pragma unroll
+    for (int ct = 0; ct < NC; ct++) {
+    Col& k = kk[ct];
+    const int col = 32 * (NC * c.wc + ct) + c.r;
     k.col = col;
     k.valid = col < NB * d.HW;
     k.board = k.valid ? col / d.HW : MAXNB;
@@ -561,6 +578,7 @@ __device__ __forceinline__ bool setup(const NetDims& d, const NetIO& io, int NB,
         if (k.valid && y >= 0 && y < d.H && x >= 0 && x < d.Wd) m |= 1u << t;
     }
     k.nbmask = m;
+    }
     return true;
 }
 
@@ -591,36 +609,44 @@ __device__ __forceinline__ void ctx_init(Ctx& c, char* smem, const LdsPlan& L, c
 // laid out [C/4][HW][4] fp32 (channel quads interleaved): a lane's four consecutive accumulator registers (channels
 // 32rt + 8qd + 4h + 0..3 of its cell) are one 16-byte access and a wave's accesses are contiguous 512-byte runs -
 // 16 instead of 64 memory instructions per lane.  mz_read_hidden un-permutes (api.cpp).
-template <int NR>
-__device__ __forceinline__ void x_load(Ctx& c, const Col& k, const float* pool, int which, int C, f32x16 (&X)[NR]) {
+template <int NR, int NC>
+__device__ __forceinline__ void x_load(Ctx& c, const Col (&kk)[NC], const float* pool, int which, int C, f32x16 (&X)[NR][NC]) {
     // unconditional loads (dead columns read slot meta[..][0], which is always a valid slot) + select:
     // a per-load branch would serialise dependent round trips
-    const int bd = k.valid ? k.board : 0;
-    const float* src = pool + (long long)c.meta[which * MAXNB + bd] * C * c.HW + (k.p + c.h * c.HW) * 4;
-    int hw = c.HW;
-    asm volatile("" : "+s"(hw));   // opaque per call: keeps the compiler from holding (and spilling) the row offsets
-    const bool keep = k.live;
 #pragma unroll
-    for (int rt = 0; rt < NR; rt++)
+    for (int ct = 0; ct < NC; ct++) {
+        const Col& k = kk[ct];
+        const int bd = k.valid ? k.board : 0;
+        const float* src = pool + (long long)c.meta[which * MAXNB + bd] * C * c.HW + (k.p + c.h * c.HW) * 4;
+        int hw = c.HW;
+        asm volatile("" : "+s"(hw));   // opaque per call: keeps the compiler from holding (and spilling) the row offsets
+        const bool keep = k.live;
 #pragma unroll
-        for (int qd = 0; qd < 4; qd++) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(src + (8 * (c.wr * NR + rt) + 2 * qd) * hw * 4);
+        for (int rt = 0; rt < NR; rt++)
 #pragma unroll
-            for (int e = 0; e < 4; e++) X[rt][4 * qd + e] = keep ? v[e] : 0.f;  // select: dead slots may hold NaN bit patterns
-        }
+            for (int qd = 0; qd < 4; qd++) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(src + (8 * (c.wr * NR + rt) + 2 * qd) * hw * 4);
+#pragma unroll
+                for (int e = 0; e < 4; e++) X[rt][ct][4 * qd + e] = keep ? v[e] : 0.f;  // select: dead slots may hold NaN bit patterns
+            }
+    }
 }
-template <int NR>
-__device__ __forceinline__ void x_store(Ctx& c, const Col& k, float* pool, int C, const f32x16 (&X)[NR]) {
-    if (!k.live) return;
-    float* dst = pool + (long long)c.meta[MAXNB + k.board] * C * c.HW + (k.p + c.h * c.HW) * 4;
-    int hw = c.HW;
-    asm volatile("" : "+s"(hw));
+template <int NR, int NC>
+__device__ __forceinline__ void x_store(Ctx& c, const Col (&kk)[NC], float* pool, int C, const f32x16 (&X)[NR][NC]) {
 #pragma unroll
-    for (int rt = 0; rt < NR; rt++)
+    for (int ct = 0; ct < NC; ct++) {
+        const Col& k = kk[ct];
+        if (!k.live) continue;
+        float* dst = pool + (long long)c.meta[MAXNB + k.board] * C * c.HW + (k.p + c.h * c.HW) * 4;
+        int hw = c.HW;
+        asm volatile("" : "+s"(hw));
 #pragma unroll
-        for (int qd = 0; qd < 4; qd++)
-            *reinterpret_cast<f32x4*>(dst + (8 * (c.wr * NR + rt) + 2 * qd) * hw * 4) =
-                (f32x4){X[rt][4 * qd], X[rt][4 * qd + 1], X[rt][4 * qd + 2], X[rt][4 * qd + 3]};
+        for (int rt = 0; rt < NR; rt++)
+#pragma unroll
+            for (int qd = 0; qd < 4; qd++)
+                *reinterpret_cast<f32x4*>(dst + (8 * (c.wr * NR + rt) + 2 * qd) * hw * 4) =
+                    (f32x4){X[rt][ct][4 * qd], X[rt][ct][4 * qd + 1], X[rt][ct][4 * qd + 2], X[rt][ct][4 * qd + 3]};
+    }
 }
 
 // ---- [conv0] + bottleneck blocks b0..b1-1 + [rescale, heads] -----------------------------------
@@ -628,29 +654,28 @@ template <class G, int IN, int OUT>
 __global__ __launch_bounds__(G::NT, G::WPE) void k_seg(NetDims d, TowerDev tw, HeadDev hd, NetIO io, LdsPlan L, int NB, int b0,
                                             int b1) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int C = G::C, CB = G::CB, NRCW = G::NRCW, WR = G::WR;
+    constexpr int C = G::C, NRCW = G::NRCW, NC = G::NC;
     constexpr int CIN0 = IN == IN_OBS ? 32 : C + 16;  // input channels of conv0, padded to 16
     constexpr int KS0 = CIN0 / 16;
     constexpr int RS0 = CIN0 * 2 + 16;
     using BS = BlockStages<G>;
-    const int tid = threadIdx.x;
     Ctx c;
     ctx_init<G>(c, smem, L, d, NB);
-    Col k;
-    if (!setup<IN>(d, io, NB, c, k)) return;
-    const int HW = d.HW, A = d.A;
+    Col k[NC];
+    if (!setup<IN, NC>(d, io, NB, c, k)) return;
+    const int HW = d.HW;
     const int g0 = blockIdx.x * NB;
     char* img = smem + L.img_off;
 
     WRing<G::NW, G::SM> ring;
-    f32x16 X[NRCW];
+    f32x16 X[NRCW][NC];
     if (IN == IN_X) {
         ring.init(tw.stream + (long long)tw.foff[b0] * 64, smem + L.ring_off, c.wave, c.lane);
         if (b0 < b1) {
             ring.issue(BS::open0);
             ring.issue(BS::open1);
         }
-        x_load<NRCW>(c, k, io.pool, 1, C, X);
+        x_load<NRCW, NC>(c, k, io.pool, 1, C, X);
         STAMP(c, ST_XLOAD);
     } else {
         ring.init(tw.stream, smem + L.ring_off, c.wave, c.lane);
@@ -659,37 +684,43 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_seg(NetDims d, TowerDev tw, H
         ring.issue(stage_frags(9 * KS0, G::NRC, G::SM, 1));
         // ---------------- input image + conv0 ----------------
         if (IN == IN_OBS) {
-            zero_acc<NRCW>(X);
+            zero_acc(X);
             if (c.wr == 0) {
-                const int g = g0 + (k.valid ? k.board : 0);
-                float y[16];
 #pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    const int ch = 16 * c.h + i;
-                    y[i] = (k.live && ch < d.O) ? io.obs[((long long)g * d.O + ch) * HW + k.p] : 0.f;
+                for (int ct = 0; ct < NC; ct++) {
+                    const int g = g0 + (k[ct].valid ? k[ct].board : 0);
+                    float y[16];
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        const int ch = 16 * c.h + i;
+                        y[i] = (k[ct].live && ch < d.O) ? io.obs[((long long)g * d.O + ch) * HW + k[ct].p] : 0.f;
+                    }
+                    *reinterpret_cast<bf16x8*>(img + k[ct].col * RS0 + (16 * c.h) * 2) = pack8(&y[0]);
+                    *reinterpret_cast<bf16x8*>(img + k[ct].col * RS0 + (16 * c.h + 8) * 2) = pack8(&y[8]);
                 }
-                *reinterpret_cast<bf16x8*>(img + k.col * RS0 + (16 * c.h) * 2) = pack8(&y[0]);
-                *reinterpret_cast<bf16x8*>(img + k.col * RS0 + (16 * c.h + 8) * 2) = pack8(&y[8]);
             }
         } else {
-            x_load<NRCW>(c, k, io.pool, 0, C, X);   // StartResidualBlock: X starts as the parent state s
+            x_load<NRCW, NC>(c, k, io.pool, 0, C, X);   // StartResidualBlock: X starts as the parent state s
 #pragma unroll
-            for (int rt = 0; rt < NRCW; rt++) {
-                float y[16];
+            for (int ct = 0; ct < NC; ct++) {
 #pragma unroll
-                for (int i = 0; i < 16; i++) y[i] = X[rt][i];
-                img_store(img, RS0, k.col, c.wr * NRCW + rt, c.h, y);
-            }
-            // ConcatInputsBlock: the one-hot action planes as channels C .. C+a-1 (padded to 16)
-            if (c.wr == 0) {
-                const int cell = c.meta[3 * MAXNB + (k.valid ? k.board : 0)];
-                float y[8];
+                for (int rt = 0; rt < NRCW; rt++) {
+                    float y[16];
 #pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const int pl = 8 * c.h + i;
-                    y[i] = (k.live && pl < d.a && cell == pl * HW + k.p) ? 1.f : 0.f;
+                    for (int i = 0; i < 16; i++) y[i] = X[rt][ct][i];
+                    img_store(img, RS0, k[ct].col, c.wr * NRCW + rt, c.h, y);
                 }
-                *reinterpret_cast<bf16x8*>(img + k.col * RS0 + (C + 8 * c.h) * 2) = pack8(&y[0]);
+                // ConcatInputsBlock: the one-hot action planes as channels C .. C+a-1 (padded to 16)
+                if (c.wr == 0) {
+                    const int cell = c.meta[3 * MAXNB + (k[ct].valid ? k[ct].board : 0)];
+                    float y[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const int pl = 8 * c.h + i;
+                        y[i] = (k[ct].live && pl < d.a && cell == pl * HW + k[ct].p) ? 1.f : 0.f;
+                    }
+                    *reinterpret_cast<bf16x8*>(img + k[ct].col * RS0 + (C + 8 * c.h) * 2) = pack8(&y[0]);
+                }
             }
         }
         conv_lds<G, KS0, 9, G::NRC, NRCW, RS0>(c, k, ring, X, b0 < b1 ? BS::open0 : 0, b0 < b1 ? BS::open1 : 0);
@@ -703,7 +734,7 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_seg(NetDims d, TowerDev tw, H
 
     if (OUT == OUT_X) {
         STAMP(c, ST_OTHER);
-        x_store<NRCW>(c, k, io.pool, C, X);
+        x_store<NRCW, NC>(c, k, io.pool, C, X);
         STAMP(c, ST_XSTORE);
         STAMP_PRINT(c, "seg");
         return;
@@ -711,26 +742,34 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_seg(NetDims d, TowerDev tw, H
     STAMP(c, ST_OTHER);
     // ---------------- RescaleBlockExt + hidden-state store ----------------
     {
-        float mn = INFINITY, mx = -INFINITY;
+        float mn[NC], mx[NC];
 #pragma unroll
-        for (int rt = 0; rt < NRCW; rt++)
+        for (int ct = 0; ct < NC; ct++) {
+            mn[ct] = INFINITY;
+            mx[ct] = -INFINITY;
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-                mn = fminf(mn, X[rt][i]);
-                mx = fmaxf(mx, X[rt][i]);
+            for (int rt = 0; rt < NRCW; rt++)
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    mn[ct] = fminf(mn[ct], X[rt][ct][i]);
+                    mx[ct] = fmaxf(mx[ct], X[rt][ct][i]);
+                }
+            if (!k[ct].valid) {
+                mn[ct] = INFINITY;
+                mx[ct] = -INFINITY;
             }
-        if (!k.valid) {
-            mn = INFINITY;
-            mx = -INFINITY;
         }
-        board_reduce<1, G::NW>(c, k, mn, mx, 0.f);
-        const float dd = fmaxf(mx - mn, 1e-5f);
+        board_reduce<1, G::NW, NC>(c, k, mn, mx, 0.f);
 #pragma unroll
-        for (int rt = 0; rt < NRCW; rt++)
+        for (int ct = 0; ct < NC; ct++) {
+            const float dd = fmaxf(mx[ct] - mn[ct], 1e-5f);
 #pragma unroll
-            for (int i = 0; i < 16; i++) X[rt][i] = (X[rt][i] - mn) / dd;
+            for (int rt = 0; rt < NRCW; rt++)
+#pragma unroll
+                for (int i = 0; i < 16; i++) X[rt][ct][i] = (X[rt][ct][i] - mn[ct]) / dd;
+        }
         STAMP(c, ST_RESCALE);
-        x_store<NRCW>(c, k, io.pool, C, X);
+        x_store<NRCW, NC>(c, k, io.pool, C, X);
         STAMP(c, ST_XSTORE);
     }
     STAMP_PRINT(c, "seg+rescale");
@@ -897,15 +936,15 @@ size_t heads_lds_bytes(const NetDims& d) {
 template <class G, int KSB>
 __global__ __launch_bounds__(G::NT, G::WPE) void k_bcast(NetDims d, TowerDev tw, NetIO io, LdsPlan L, int NB, int blk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int C = G::C, NRC = G::NRC, NRCW = G::NRCW;
+    constexpr int C = G::C, NRC = G::NRC, NRCW = G::NRCW, NC = G::NC;
     constexpr int QT = (KSB + 1) / 2, KP = 16 * KSB;
     constexpr int RS = C * 2 + 16;
     constexpr int KSC = C / 16;
     constexpr int FS0 = stage_frags(KSC, NRC, G::SM, 0), FS1 = stage_frags(KSC, NRC, G::SM, 1);
     Ctx c;
     ctx_init<G>(c, smem, L, d, NB);
-    Col k;
-    if (!setup<IN_X>(d, io, NB, c, k)) return;
+    Col k[NC];
+    if (!setup<IN_X, NC>(d, io, NB, c, k)) return;
     const long long e = c.HW + 1;
     const u32x4* gb1 = tw.gb + tw.gboff[blk];
     const u32x4* gb2 = gb1 + NRC * 8 * e;
@@ -919,20 +958,24 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_bcast(NetDims d, TowerDev tw,
     ring.init(tw.stream + (long long)tw.foff[blk] * 64, smem + L.ring_off, c.wave, c.lane);
     ring.issue(FS0);
     ring.issue(FS1);
-    f32x16 X[NRCW];
-    x_load<NRCW>(c, k, io.pool, 1, C, X);
+    f32x16 X[NRCW][NC];
+    x_load<NRCW, NC>(c, k, io.pool, 1, C, X);
     {
         // LN1 -> image -> c1 (1x1, C -> C); this wave's share of the output rows stays in registers
-        f32x16 a[NRCW];
-        ln_to_image<NRCW, G::NW>(c, k, gb1, X, C, RS);
-        zero_acc<NRCW>(a);
+        f32x16 a[NRCW][NC];
+        ln_to_image<NRCW, G::NW, NC>(c, k, gb1, X, C, RS);
+        zero_acc(a);
         conv_lds<G, KSC, 1, NRC, NRCW, RS>(c, k, ring, a, 0, 0);
         STAMP(c, ST_OTHER);
         // LN2 + ReLU -> bf16 -> transposed image TB (the statistics barrier proves that every wave has
         // finished c1, so the ring under TB is dead)
-        u32x4 g[4];
-        float mean, rstd;
-        ln_stats<NRCW, G::NW>(c, k, a, C, mean, rstd);
+        u32x4 g[NC][NRCW][4];   // requested before the statistics round trip
+#pragma unroll
+        for (int ct = 0; ct < NC; ct++)
+#pragma unroll
+            for (int rt = 0; rt < NRCW; rt++) gb_load(gb2, c, k[ct], c.wr * NRCW + rt, g[ct][rt]);
+        float mean[NC], rstd[NC];
+        ln_stats<NRCW, G::NW, NC>(c, k, a, C, mean, rstd);
         for (int i = threadIdx.x; i < C * NB * (KP - c.HW); i += G::NT) {  // zero the K padding of every board
             const int padw = KP - c.HW;
             const int ch = i / (NB * padw), rem = i - ch * (NB * padw);
@@ -940,19 +983,20 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_bcast(NetDims d, TowerDev tw,
             *reinterpret_cast<__bf16*>(tb + ch * TBS + (bd * KP + c.HW + pp) * 2) = (__bf16)0.f;
         }
 #pragma unroll
-        for (int rt = 0; rt < NRCW; rt++) {
-            gb_load(gb2, c, k, c.wr * NRCW + rt, g);
-            float y[16];
-            ln_apply(a[rt], mean, rstd, g, y);
-            if (k.valid) {
-                const int cbase = k.board * KP + k.p;
+        for (int ct = 0; ct < NC; ct++)
 #pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    const int ch = 32 * (c.wr * NRCW + rt) + (i & 3) + 8 * (i >> 2) + 4 * c.h;
-                    *reinterpret_cast<__bf16*>(tb + ch * TBS + cbase * 2) = (__bf16)y[i];
+            for (int rt = 0; rt < NRCW; rt++) {
+                float y[16];
+                ln_apply(a[rt][ct], mean[ct], rstd[ct], g[ct][rt], y);
+                if (k[ct].valid) {
+                    const int cbase = k[ct].board * KP + k[ct].p;
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        const int ch = 32 * (c.wr * NRCW + rt) + (i & 3) + 8 * (i >> 2) + 4 * c.h;
+                        *reinterpret_cast<__bf16*>(tb + ch * TBS + cbase * 2) = (__bf16)y[i];
+                    }
                 }
             }
-        }
     }
     // broadcast-linear B fragments and bias (requested here, once the c1 tiles are dead): lane (q = 32qt + r, h) holds Wb[q][16ks + 8h + j]
     u32x4 wreg[KSB][QT];
@@ -973,7 +1017,24 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_bcast(NetDims d, TowerDev tw,
     float* ipart = c.wpart + 2 * MAXNB * G::NW * 2;   // [items][2]
     float* bstat = ipart + 2 * 256;                   // [MAXNB][2]
     const int nitems = NB * NRC;
+    // the residual stream for c2 is requested here (it was not held in registers through c1 and the transpose), so
+    // its round trip runs under the two passes
+    x_load<NRCW, NC>(c, k, io.pool, 1, C, X);
+    // gamma/beta of LN3 for (row tile rtw, cells q): 4 x 16-byte loads, requested one (item, q tile) ahead in pass 1
+    auto g3_load = [&](int it, int qt, u32x4(&g)[4]) {
+        if (it >= nitems) return;
+        const int rtw = it % NRC;
+        const int q = 32 * qt + c.r;
+        const unsigned stride = (unsigned)(c.HW + 1) * 32u;
+        const unsigned off = (unsigned)(c.h * (c.HW + 1) + (q < c.HW ? q : c.HW)) * 16u + (unsigned)(rtw * 4) * stride;
+#pragma unroll
+        for (int qd = 0; qd < 4; qd++)
+            g[qd] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(gb3) + off + qd * stride);
+        __builtin_amdgcn_sched_barrier(0x38F);
+    };
     for (int pass = 0; pass < 2; pass++) {
+        u32x4 gn[4];
+        if (pass == 1) g3_load(c.wave, 0, gn);
         for (int it = c.wave; it < nitems; it += G::NW) {
             const int bd = it / NRC, rtw = it - bd * NRC;
             const char* arow = tb + (32 * rtw + c.r) * TBS + (bd * KP + 8 * c.h) * 2;
@@ -984,12 +1045,10 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_bcast(NetDims d, TowerDev tw,
                 const bool qv = q < c.HW;
                 u32x4 g[4];
                 if (pass == 1) {
-                    const unsigned stride = (unsigned)(c.HW + 1) * 32u;
-                    const unsigned off = (unsigned)(c.h * (c.HW + 1) + (qv ? q : c.HW)) * 16u + (unsigned)(rtw * 4) * stride;
 #pragma unroll
-                    for (int qd = 0; qd < 4; qd++)
-                        g[qd] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(gb3) + off + qd * stride);
-                    __builtin_amdgcn_sched_barrier(0x38F);
+                    for (int qd = 0; qd < 4; qd++) g[qd] = gn[qd];
+                    if (qt + 1 < QT) g3_load(it, qt + 1, gn);
+                    else g3_load(it + G::NW, 0, gn);
                 }
                 f32x16 acc;
 #pragma unroll
@@ -1047,21 +1106,22 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_bcast(NetDims d, TowerDev tw,
         }
     }
     // padded columns of the image (beyond NB*HW) feed only padded outputs, but must be finite
-    if (!k.valid) {
 #pragma unroll
-        for (int rt = 0; rt < NRCW; rt++) {
-            const unsigned o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            img_store_pk(img, RS, k.col, c.wr * NRCW + rt, c.h, o);
+    for (int ct = 0; ct < NC; ct++)
+        if (!k[ct].valid) {
+#pragma unroll
+            for (int rt = 0; rt < NRCW; rt++) {
+                const unsigned o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                img_store_pk(img, RS, k[ct].col, c.wr * NRCW + rt, c.h, o);
+            }
         }
-    }
     lds_barrier();   // image complete, TB dead: region 2 is the ring again
     STAMP(c, ST_BCAST);
-    // c2: 1x1 conv C -> C on the image (own columns), accumulated into X (re-read: it was not held in registers)
+    // c2: 1x1 conv C -> C on the image (own columns), accumulated into X
     ring.issue(FS0);
     ring.issue(FS1);
-    x_load<NRCW>(c, k, io.pool, 1, C, X);
     conv_lds<G, KSC, 1, NRC, NRCW, RS>(c, k, ring, X, 0, 0);
-    x_store<NRCW>(c, k, io.pool, C, X);
+    x_store<NRCW, NC>(c, k, io.pool, C, X);
     STAMP(c, ST_XSTORE);
     STAMP_PRINT(c, "bcast");
 }
@@ -1127,7 +1187,7 @@ struct TowerHost {
 
 struct MfmaNet {
     NetDims d{};
-    int geom = 0, NB = 0, WR = 1, NW = 8, SM = 32, COLS = 256;
+    int geom = 0, NB = 0, WR = 1, NW = 8, SM = 32, NC = 1, COLS = 256;
     LdsPlan Lseg{}, Lbc{};
     void* bufs[16] = {nullptr};
     int nbufs = 0;
@@ -1214,23 +1274,21 @@ MfmaNet* mfma_create(const NetDims& d, int /*max_batch*/, std::string* err) {
     n->d = d;
     // Workgroup geometry (see Geo): numChannels 256 -> 2x4 waves on 128 columns; numChannels 128 -> 1x8 waves on 256
     // columns (measured best on Go 9x9: 1.31 ms per recurrentInference of 4096 boards against 1.55 / 1.58 / 1.42 ms
-    // for the 2x3, 2x4 and 2x8 grids, which trade column packing for a second workgroup per CU).  MZ_GEOM picks
-    // one of the other grids (diagnostics).
-    struct GeomDesc { int WR, NW, SM; };
-    static const GeomDesc kGeom[5] = {{1, 8, 24}, {2, 6, 16}, {2, 8, 16}, {2, 8, 24}, {2, 16, 32}};
-    if (d.C == 256) {
-        n->geom = 3;
-    } else {
-        n->geom = 0;
-        if (const char* e = std::getenv("MZ_GEOM")) {
-            const int g = std::atoi(e);
-            if (g == 0) n->geom = g;   // the 2x3 / 2x4 / 2x8 grids (1, 2, 4) are not instantiated in this build
-        }
-    }
+    // for the 2x3, 2x4 and 2x8 grids, which trade column packing for a second workgroup per CU).
+    // MZ_GEOM=1 (numChannels 128 only) selects 4 waves x 2 column tiles instead: one wave per SIMD with the whole
+    // register file, 1.0 instead of 1.5 LDS reads per MFMA in the 3x3 convs.  Measured 15 % slower on Go 9x9
+    // (5.70 against 4.96 ms at 16384 boards): the matrix loops gain, but a lone wave per SIMD runs the LayerNorm
+    // phases (dependent VALU chains, LDS and gamma/beta round trips) with nothing to overlap them.
+    struct GeomDesc { int WR, NW, SM, NC; };
+    static const GeomDesc kGeom[3] = {{1, 8, 24, 1}, {2, 8, 24, 1}, {1, 4, 24, 2}};
+    n->geom = d.C == 256 ? 1 : 0;
+    if (const char* e = std::getenv("MZ_GEOM"))
+        if (std::atoi(e) == 1 && d.C == 128) n->geom = 2;
     n->WR = kGeom[n->geom].WR;
     n->NW = kGeom[n->geom].NW;
     n->SM = kGeom[n->geom].SM;
-    n->COLS = 32 * (n->NW / n->WR);
+    n->NC = kGeom[n->geom].NC;
+    n->COLS = 32 * (n->NW / n->WR) * n->NC;
     n->NB = n->COLS / d.HW;
     if (n->NB > MAXNB) n->NB = MAXNB;
     if (n->NB < 1) {
@@ -1449,7 +1507,8 @@ int mfma_forward(MfmaNet* n, hipStream_t st, bool initial, const NetDims& d, con
     }
     switch (n->geom) {
         case 0: return forward_t<Geo<128, 64, 1, 8, 24, 2>>(n, st, initial, d, io);
-        default: return forward_t<Geo<256, 128, 2, 8, 24, 2>>(n, st, initial, d, io);
+        case 1: return forward_t<Geo<256, 128, 2, 8, 24, 2>>(n, st, initial, d, io);
+        default: return forward_t<Geo<128, 64, 1, 4, 24, 1, 2>>(n, st, initial, d, io);
     }
 }
 
