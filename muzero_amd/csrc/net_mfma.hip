@@ -95,6 +95,7 @@ struct HeadDev {
     const float* vfc1b; // [C]
     const float* vfc2w; // [C]
     const float* vfc2b; // [1]
+    float* hfeat;       // [max batch][3][HW]: outputs of the three head convs, written by the tower's last launch
 };
 // Byte offsets into the workgroup's one dynamic LDS array.
 struct LdsPlan {
@@ -772,14 +773,60 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_seg(NetDims d, TowerDev tw, H
         x_store<NRCW, NC>(c, k, io.pool, C, X);
         STAMP(c, ST_XSTORE);
     }
+    // ---------------- the 1x1 convs that open the prediction heads (C -> policy 0, policy 1, value) -------------
+    // Taken here off the registers, so that k_heads reads 3 values per cell instead of the whole hidden state again.
+    // A lane holds 16 * NRCW channels of its cell: per-lane partial dot products -> LDS (the image is dead) -> the
+    // 2 * WR partials of a cell are summed in a fixed order by the lane (wr = 0, h = 0) of that column.
+    {
+        float* hpart = reinterpret_cast<float*>(smem + L.img_off);   // [2 * WR][3][COLS]
+        float part[NC][3];
+#pragma unroll
+        for (int ct = 0; ct < NC; ct++)
+#pragma unroll
+            for (int o = 0; o < 3; o++) part[ct][o] = 0.f;
+#pragma unroll
+        for (int rt = 0; rt < NRCW; rt++) {
+            f32x4 w[3][4];
+#pragma unroll
+            for (int o = 0; o < 3; o++)
+#pragma unroll
+                for (int qd = 0; qd < 4; qd++)
+                    w[o][qd] = *reinterpret_cast<const f32x4*>(hd.hconv + o * C + 32 * (c.wr * NRCW + rt) + 8 * qd + 4 * c.h);
+#pragma unroll
+            for (int ct = 0; ct < NC; ct++)
+#pragma unroll
+                for (int o = 0; o < 3; o++)
+#pragma unroll
+                    for (int i = 0; i < 16; i++) part[ct][o] = fmaf(X[rt][ct][i], w[o][i >> 2][i & 3], part[ct][o]);
+        }
+#pragma unroll
+        for (int ct = 0; ct < NC; ct++)
+#pragma unroll
+            for (int o = 0; o < 3; o++) hpart[((c.wr * 2 + c.h) * 3 + o) * G::COLS + k[ct].col] = part[ct][o];
+        lds_barrier();
+        if (c.wr == 0 && c.h == 0) {
+#pragma unroll
+            for (int ct = 0; ct < NC; ct++) {
+                if (!k[ct].live) continue;
+                float* dst = hd.hfeat + ((long long)(g0 + k[ct].board) * 3) * HW + k[ct].p;
+#pragma unroll
+                for (int o = 0; o < 3; o++) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 2 * G::WR; j++) sum += hpart[(j * 3 + o) * G::COLS + k[ct].col];
+                    dst[o * HW] = sum;
+                }
+            }
+        }
+    }
     STAMP_PRINT(c, "seg+rescale");
 }
 
 // ---- PredictionBlock (B/c_mainfunctions/PredictionBlock.java:46-84) ------------------------------
 // One 256-thread workgroup per HS = 4 samples, many workgroups per CU: the heads are small latency chains
-// (1x1 convs -> LayerNorm -> linears -> softmax / tanh), so they run at high occupancy off the freshly
-// written hidden state instead of serialising the big workgroups of the tower kernels.  Wave s owns sample
-// s for the convs, the LayerNorms and the outputs (no workgroup barrier there); the two linears are shared
+// (1x1 convs -> LayerNorm -> linears -> softmax / tanh), so they run at high occupancy instead of serialising the
+// big workgroups of the tower kernels.  The three 1x1 convs are taken by the tower's last launch off its registers
+// (HeadDev::hfeat).  Wave s owns sample s for the LayerNorms and the outputs (no workgroup barrier there); the two linears are shared
 // work: an item = one output of one K chunk, its weights loaded once and applied to all four samples.
 // All fp32: the per-board LayerNorm over a single HW-value channel amplifies rounding of whatever feeds it.
 constexpr int HT = 256;      // threads
@@ -827,24 +874,16 @@ __global__ __launch_bounds__(HT) void k_heads(NetDims d, HeadDev hd, NetIO io) {
         float a00 = 0.f, a01 = 0.f, a02 = 0.f, a10 = 0.f, a11 = 0.f, a12 = 0.f;
         const bool v0 = lane < HW, v1 = lane + 64 < HW;
         if (live) {
-            const float* h = io.pool + (long long)io.dst_slot[g] * C * HW;   // [C/4][HW][4]
-            const float* h0 = h + (v0 ? lane : 0) * 4;
-            const float* h1 = h + (v1 ? lane + 64 : 0) * 4;
-#pragma unroll 8
-            for (int cq = 0; cq < C / 4; cq++) {
-                const f32x4 x0 = *reinterpret_cast<const f32x4*>(h0 + cq * HW * 4);
-                const f32x4 x1 = *reinterpret_cast<const f32x4*>(h1 + cq * HW * 4);
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const int ch = 4 * cq + e;
-                    const float w0 = hd.hconv[ch], w1 = hd.hconv[C + ch], w2 = hd.hconv[2 * C + ch];
-                    a00 = fmaf(x0[e], w0, a00);
-                    a01 = fmaf(x0[e], w1, a01);
-                    a02 = fmaf(x0[e], w2, a02);
-                    a10 = fmaf(x1[e], w0, a10);
-                    a11 = fmaf(x1[e], w1, a11);
-                    a12 = fmaf(x1[e], w2, a12);
-                }
+            const float* hf = hd.hfeat + (long long)g * 3 * HW;   // written by k_seg<.., OUT_FINAL>
+            if (v0) {
+                a00 = hf[lane];
+                a01 = hf[HW + lane];
+                a02 = hf[2 * HW + lane];
+            }
+            if (v1) {
+                a10 = hf[lane + 64];
+                a11 = hf[HW + lane + 64];
+                a12 = hf[2 * HW + lane + 64];
             }
         }
         // LayerNorm over (2, HW) for the policy features and over (1, HW) for the value features
@@ -1191,6 +1230,8 @@ struct MfmaNet {
     LdsPlan Lseg{}, Lbc{};
     void* bufs[16] = {nullptr};
     int nbufs = 0;
+    float* hfeat = nullptr;   // [max_batch][3][HW]
+    int max_batch = 0;
     TowerDev tw[2]{};
     HeadDev hd{};
     bool packed = false;
@@ -1263,7 +1304,7 @@ int upload(MfmaNet* n, const std::vector<T>& v, const void** out, size_t slack_b
 
 }  // namespace
 
-MfmaNet* mfma_create(const NetDims& d, int /*max_batch*/, std::string* err) {
+MfmaNet* mfma_create(const NetDims& d, int max_batch, std::string* err) {
     if (!shape_supported(d)) {
         if (err)
             *err = "bf16 MFMA path supports numChannels/numBottleneckChannels 128/64 and 256/128 on boards of 4..96 "
@@ -1305,12 +1346,19 @@ MfmaNet* mfma_create(const NetDims& d, int /*max_batch*/, std::string* err) {
         delete n;
         return nullptr;
     }
+    n->max_batch = max_batch > 0 ? max_batch : 1;
+    if (hipMalloc(reinterpret_cast<void**>(&n->hfeat), (size_t)n->max_batch * 3 * d.HW * sizeof(float)) != hipSuccess) {
+        if (err) *err = "hipMalloc failed in mfma_create";
+        delete n;
+        return nullptr;
+    }
     return n;
 }
 
 void mfma_destroy(MfmaNet* n) {
     if (!n) return;
     for (int i = 0; i < n->nbufs; i++) (void)hipFree(n->bufs[i]);
+    if (n->hfeat) (void)hipFree(n->hfeat);
     delete n;
 }
 
@@ -1422,7 +1470,7 @@ int mfma_pack_weights(MfmaNet* n, const NetDims& d, const float* blob, size_t co
     if (upload(n, hp, &p, 64, err)) return -1;
     const float* hb = (const float*)p;
     n->hd = HeadDev{hb + o_hconv, hb + o_plng, hb + o_plnb, hb + o_pfcw, hb + o_pfcb, hb + o_vlng,
-                    hb + o_vlnb, hb + o_vfc1w, hb + o_vfc1b, hb + o_vfc2w, hb + o_vfc2b};
+                    hb + o_vlnb, hb + o_vfc1w, hb + o_vfc1b, hb + o_vfc2w, hb + o_vfc2b, n->hfeat};
     n->packed = true;
     return 0;
 }
@@ -1503,6 +1551,10 @@ int forward_t(MfmaNet* n, hipStream_t st, bool initial, const NetDims& d, const 
 int mfma_forward(MfmaNet* n, hipStream_t st, bool initial, const NetDims& d, const NetIO& io, std::string* err) {
     if (!n || !n->packed) {
         if (err) *err = "mfma weights not packed";
+        return -1;
+    }
+    if (io.B > n->max_batch) {
+        if (err) *err = "batch exceeds the context's inference capacity";
         return -1;
     }
     switch (n->geom) {
