@@ -487,6 +487,81 @@ __device__ __forceinline__ void conv_lds(Ctx& c, const Col (&k)[G::NC], WRing<G:
     STAMP(c, ST_MMA);
 }
 
+// relu(LN(v)) of this wave's NR row tiles kept in registers as MFMA B operands (WR = 1: the wave holds every
+// channel of its columns).  A lane's 16 accumulator rows of row tile rt are the channels 32rt + 8qd + 4h + e; packed
+// in that order they are the B operands of two k-steps whose k index runs k = 8h + j <-> channel
+// 32rt + 16s + 4h + (j & 3) + 8(j >> 2) (s = k-step parity) - the order pack_conv_kperm gives the A fragments.
+// No LDS image, no ds_write, no B reads for the 1x1 convs.
+template <int NR, int NW, int NC>
+__device__ __forceinline__ void ln_to_regs(Ctx& c, const Col (&k)[NC], const u32x4* gb, const f32x16 (&v)[NR][NC], int nch,
+                                           u32x4 (&bop)[2 * NR][NC]) {
+    u32x4 g[NR][NC][4];
+#pragma unroll
+    for (int rt = 0; rt < (NR < 2 ? NR : 2); rt++)
+#pragma unroll
+        for (int ct = 0; ct < NC; ct++) gb_load(gb, c, k[ct], rt, g[rt][ct]);
+    float mean[NC], rstd[NC];
+    STAMP(c, ST_OTHER);
+    ln_stats<NR, NW, NC>(c, k, v, nch, mean, rstd);
+    STAMP(c, ST_STATS);
+#pragma unroll
+    for (int rt = 2; rt < NR; rt++)
+#pragma unroll
+        for (int ct = 0; ct < NC; ct++) gb_load(gb, c, k[ct], rt, g[rt][ct]);
+#pragma unroll
+    for (int rt = 0; rt < NR; rt++)
+#pragma unroll
+        for (int ct = 0; ct < NC; ct++) {
+            unsigned o[8];
+            ln_apply_pk(v[rt][ct], rstd[ct], -mean[ct] * rstd[ct], g[rt][ct], o);   // padded columns: gamma = beta = 0 -> zeros
+            bop[2 * rt][ct] = (u32x4){o[0], o[1], o[2], o[3]};
+            bop[2 * rt + 1][ct] = (u32x4){o[4], o[5], o[6], o[7]};
+        }
+    STAMP(c, ST_NORM);
+}
+
+// acc[ro][ct] += W * bop for a 1x1 conv whose B operands are in registers (KS k-steps, fragments (ks, ro) in k-permuted
+// order); same ring protocol as conv_lds.
+template <class G, int KS, int NROT>
+__device__ __forceinline__ void conv_regs(Ctx& c, WRing<G::NW, G::SM>& ring, const u32x4 (&bop)[KS][G::NC],
+                                          f32x16 (&acc)[NROT][G::NC], int after1, int after2) {
+    constexpr int NC = G::NC;
+    constexpr int SK = stage_ksteps(KS, NROT, G::SM);
+    constexpr int NST = num_stages(KS, NROT, G::SM);
+    const char* slot = nullptr;
+    auto load_a = [&](int kk, bf16x8(&a)[NROT]) {
+#pragma unroll
+        for (int ro = 0; ro < NROT; ro++)
+            a[ro] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(slot + ((kk % SK) * NROT + ro) * 1024));
+    };
+    bf16x8 acur[NROT], anxt[NROT];
+#pragma unroll
+    for (int kk = 0; kk < KS; kk++) {
+        if (kk % SK == 0) {
+            STAMP(c, kk == 0 ? ST_OTHER : ST_MMA);
+            slot = ring.acquire() + c.lane * 16;
+            STAMP(c, ST_ACQ);
+            const int j = kk / SK + 2;
+            ring.issue(j < NST ? stage_frags(KS, NROT, G::SM, j) : (j == NST ? after1 : after2));
+            load_a(kk, acur);
+        }
+        const bool more = kk + 1 < KS && (kk + 1) % SK != 0;
+        if (more) load_a(kk + 1, anxt);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ro = 0; ro < NROT; ro++)
+#pragma unroll
+            for (int ct = 0; ct < NC; ct++)
+                acc[ro][ct] = MFMA(acur[ro], __builtin_bit_cast(bf16x8, bop[kk][ct]), acc[ro][ct]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) {
+#pragma unroll
+            for (int ro = 0; ro < NROT; ro++) acur[ro] = anxt[ro];
+        }
+    }
+    STAMP(c, ST_MMA);
+}
+
 template <int NR, int NC>
 __device__ __forceinline__ void zero_acc(f32x16 (&a)[NR][NC]) {
 #pragma unroll
@@ -526,10 +601,17 @@ __device__ __forceinline__ void bottleneck(Ctx& c, const Col (&k)[G::NC], WRing<
     const u32x4* gb4 = gb3 + G::NRB * 8 * e;
     f32x16 a1[G::NRBW][G::NC];
 
-    // LN1 -> image -> c1 (1x1, C -> CB)
-    ln_to_image<G::NRCW, G::NW, G::NC>(c, k, gb1, X, C, RSC);
-    zero_acc(a1);
-    conv_lds<G, KSC, 1, G::NRB, G::NRBW, RSC>(c, k, ring, a1, BS::c2(0), BS::c2(1));
+    // LN1 -> c1 (1x1, C -> CB): B operands from registers when the wave holds all channels, else through the image
+    if constexpr (G::WR == 1) {
+        u32x4 bop[KSC][G::NC];
+        ln_to_regs<G::NRC, G::NW, G::NC>(c, k, gb1, X, C, bop);
+        zero_acc(a1);
+        conv_regs<G, KSC, G::NRB>(c, ring, bop, a1, BS::c2(0), BS::c2(1));
+    } else {
+        ln_to_image<G::NRCW, G::NW, G::NC>(c, k, gb1, X, C, RSC);
+        zero_acc(a1);
+        conv_lds<G, KSC, 1, G::NRB, G::NRBW, RSC>(c, k, ring, a1, BS::c2(0), BS::c2(1));
+    }
     // LN2 -> image -> c2 (3x3), LN3 -> image -> c3 (3x3); the image is consumed before a1 is rewritten
 #pragma unroll
     for (int layer = 0; layer < 2; layer++) {
@@ -538,9 +620,15 @@ __device__ __forceinline__ void bottleneck(Ctx& c, const Col (&k)[G::NC], WRing<
         conv_lds<G, KSB, 9, G::NRB, G::NRBW, RSB>(c, k, ring, a1, layer == 0 ? BS::c2(0) : BS::c4(0),
                                                   layer == 0 ? BS::c2(1) : (BS::n4 > 1 ? BS::c4(1) : nx0));
     }
-    // LN4 -> image -> c4 (1x1, CB -> C) accumulated into X
-    ln_to_image<G::NRBW, G::NW, G::NC>(c, k, gb4, a1, CB, RSB);
-    conv_lds<G, KSB, 1, G::NRC, G::NRCW, RSB>(c, k, ring, X, nx0, nx1);
+    // LN4 -> c4 (1x1, CB -> C) accumulated into X
+    if constexpr (G::WR == 1) {
+        u32x4 bop[KSB][G::NC];
+        ln_to_regs<G::NRB, G::NW, G::NC>(c, k, gb4, a1, CB, bop);
+        conv_regs<G, KSB, G::NRC>(c, ring, bop, X, nx0, nx1);
+    } else {
+        ln_to_image<G::NRBW, G::NW, G::NC>(c, k, gb4, a1, CB, RSB);
+        conv_lds<G, KSB, 1, G::NRC, G::NRCW, RSB>(c, k, ring, X, nx0, nx1);
+    }
 }
 
 // ---- shared prologue: per-board meta data and per-lane column info -----------------------------
@@ -1203,6 +1291,16 @@ void pack_conv(FragWriter& fw, const float* W, int Cout, int Cin, int taps, int 
                     return W[((size_t)(32 * ro + row) * Cin + ci) * taps + t];
                 });
 }
+// 1x1 conv whose B operands come from registers (ln_to_regs): k-step ks, k index kp <-> input channel
+// 32(ks >> 1) + 16(ks & 1) + 4(kp >> 3) + (kp & 3) + 8((kp & 7) >> 2)
+void pack_conv_kperm(FragWriter& fw, const float* W, int Cout, int Cin) {
+    for (int ks = 0; ks < Cin / 16; ks++)
+        for (int ro = 0; ro < Cout / 32; ro++)
+            fw.frag([&](int row, int kp) {
+                const int ci = 32 * (ks >> 1) + 16 * (ks & 1) + 4 * (kp >> 3) + (kp & 3) + 8 * ((kp & 7) >> 2);
+                return W[(size_t)(32 * ro + row) * Cin + ci];
+            });
+}
 // gamma/beta [Cn][HW] -> fp16 [rt][qd][h][HW+1]{g0..3, b0..3}: lane (cell p, half h) of row tile rt reads
 // channels 32rt + 8qd + 4h + e; entry HW is all zero (padded columns)
 void pack_gb(std::vector<unsigned short>& out, const float* g, const float* b, int Cn, int HW) {
@@ -1391,10 +1489,12 @@ int mfma_pack_weights(MfmaNet* n, const NetDims& d, const float* blob, size_t co
                 const float *g2 = take((size_t)Cb * HW), *b2 = take((size_t)Cb * HW), *c2 = take((size_t)Cb * Cb * 9);
                 const float *g3 = take((size_t)Cb * HW), *b3 = take((size_t)Cb * HW), *c3 = take((size_t)Cb * Cb * 9);
                 const float *g4 = take((size_t)Cb * HW), *b4 = take((size_t)Cb * HW), *c4 = take((size_t)C * Cb);
-                pack_conv(fw, c1, Cb, C, 1, C);
+                if (n->WR == 1) pack_conv_kperm(fw, c1, Cb, C);
+                else pack_conv(fw, c1, Cb, C, 1, C);
                 pack_conv(fw, c2, Cb, Cb, 9, Cb);
                 pack_conv(fw, c3, Cb, Cb, 9, Cb);
-                pack_conv(fw, c4, C, Cb, 1, Cb);
+                if (n->WR == 1) pack_conv_kperm(fw, c4, C, Cb);
+                else pack_conv(fw, c4, C, Cb, 1, Cb);
                 pack_gb(T.gb, g1, b1, C, HW);
                 pack_gb(T.gb, g2, b2, Cb, HW);
                 pack_gb(T.gb, g3, b3, Cb, HW);
