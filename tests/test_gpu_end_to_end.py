@@ -154,3 +154,41 @@ def test_single_game_and_one_legal_action_shortcut_bf16():
     assert one["action"][0] == got["action"][0]
     np.testing.assert_array_equal(one["visit_counts"][0], got["visit_counts"][0])
     ctx.close()
+
+
+def test_bench_size_properties_go9_bf16():
+    """The bench.py workload (16384 Go 9x9 games, real bf16 nets, one planned move): size-independent properties,
+    and games are independent units - the first 99 games searched alone (same position in their workgroup tiles)
+    give bit-identical actions, visit counts and targets."""
+    spec = netspec.spec_go9()
+    c = H.SEARCH_CASES["go9"]
+    B, A, n = 16384, spec.action_space, c["n"]
+    rng = np.random.default_rng(21)
+    w = netspec.pack_blob(spec, netspec.random_weights(spec, seed=1))
+    obs = H.synthetic_obs(rng, spec, B)
+    legal = np.ones((B, A), np.uint8)
+    legal[7, :40] = 0
+    g = H.gumbel_noise(rng, B, A)
+
+    def run(nb):
+        ctx = capi.Context(capi.make_config(spec, n, c["m"], c["c_visit"], known_bounds=c["bounds"], max_games=nb,
+                                            precision=capi.PRECISION_BF16))
+        ctx.load_weights(w)
+        ctx.set_action_cells(netspec.action_cells_board(spec))
+        out = ctx.search_moves(nb, obs[:nb], legal[:nb], gumbel=g[:nb])
+        ctx.close()
+        return out
+
+    got = run(B)
+    assert (got["status"] == 0).all()
+    assert (got["sims_run"] == n).all()
+    assert (got["visit_counts"].sum(1) == n).all()
+    assert ((got["visit_counts"] > 0).sum(1) <= c["m"]).all()
+    assert (legal[np.arange(B), got["action"]] == 1).all()
+    assert (got["visit_counts"][legal == 0] == 0).all() and (got["policy_target"][legal == 0] == 0).all()
+    np.testing.assert_allclose(got["policy_target"].sum(1), 1.0, atol=1e-5)
+    assert np.isfinite(got["root_value_target"]).all() and (np.abs(got["root_value_target"]) <= 81.0 + 1e-3).all()
+    assert len(np.unique(got["action"])) > 8      # the nets see different boards: not one constant answer
+    sub = run(99)
+    for key in ("action", "visit_counts", "policy_target", "root_value_target", "v_mix", "root_value_inference"):
+        np.testing.assert_array_equal(sub[key], got[key][:99])
