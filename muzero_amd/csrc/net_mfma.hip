@@ -738,83 +738,14 @@ __device__ __forceinline__ void x_store(Ctx& c, const Col (&kk)[NC], float* pool
     }
 }
 
-// ---- [conv0] + bottleneck blocks b0..b1-1 + [rescale, heads] -----------------------------------
-template <class G, int IN, int OUT>
-__global__ __launch_bounds__(G::NT, G::WPE) void k_seg(NetDims d, TowerDev tw, HeadDev hd, NetIO io, LdsPlan L, int NB, int b0,
-                                            int b1) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// ---- bottleneck blocks b0..b1-1, then the X store or [rescale + hidden-state store + head convs] ----------
+template <class G, int OUT>
+__device__ __forceinline__ void seg_rest(Ctx& c, const Col (&k)[G::NC], const NetDims& d, const TowerDev& tw, const HeadDev& hd,
+                                         const NetIO& io, const LdsPlan& L, char* smem, WRing<G::NW, G::SM>& ring,
+                                         f32x16 (&X)[G::NRCW][G::NC], int NB, int b0, int b1) {
     constexpr int C = G::C, NRCW = G::NRCW, NC = G::NC;
-    constexpr int CIN0 = IN == IN_OBS ? 32 : C + 16;  // input channels of conv0, padded to 16
-    constexpr int KS0 = CIN0 / 16;
-    constexpr int RS0 = CIN0 * 2 + 16;
-    using BS = BlockStages<G>;
-    Ctx c;
-    ctx_init<G>(c, smem, L, d, NB);
-    Col k[NC];
-    if (!setup<IN, NC>(d, io, NB, c, k)) return;
     const int HW = d.HW;
     const int g0 = blockIdx.x * NB;
-    char* img = smem + L.img_off;
-
-    WRing<G::NW, G::SM> ring;
-    f32x16 X[NRCW][NC];
-    if (IN == IN_X) {
-        ring.init(tw.stream + (long long)tw.foff[b0] * 64, smem + L.ring_off, c.wave, c.lane);
-        if (b0 < b1) {
-            ring.issue(BS::open0);
-            ring.issue(BS::open1);
-        }
-        x_load<NRCW, NC>(c, k, io.pool, 1, C, X);
-        STAMP(c, ST_XLOAD);
-    } else {
-        ring.init(tw.stream, smem + L.ring_off, c.wave, c.lane);
-        static_assert(num_stages(9 * KS0, G::NRC, G::SM) >= 2, "conv0 spans at least two stages");
-        ring.issue(stage_frags(9 * KS0, G::NRC, G::SM, 0));
-        ring.issue(stage_frags(9 * KS0, G::NRC, G::SM, 1));
-        // ---------------- input image + conv0 ----------------
-        if (IN == IN_OBS) {
-            zero_acc(X);
-            if (c.wr == 0) {
-#pragma unroll
-                for (int ct = 0; ct < NC; ct++) {
-                    const int g = g0 + (k[ct].valid ? k[ct].board : 0);
-                    float y[16];
-#pragma unroll
-                    for (int i = 0; i < 16; i++) {
-                        const int ch = 16 * c.h + i;
-                        y[i] = (k[ct].live && ch < d.O) ? io.obs[((long long)g * d.O + ch) * HW + k[ct].p] : 0.f;
-                    }
-                    *reinterpret_cast<bf16x8*>(img + k[ct].col * RS0 + (16 * c.h) * 2) = pack8(&y[0]);
-                    *reinterpret_cast<bf16x8*>(img + k[ct].col * RS0 + (16 * c.h + 8) * 2) = pack8(&y[8]);
-                }
-            }
-        } else {
-            x_load<NRCW, NC>(c, k, io.pool, 0, C, X);   // StartResidualBlock: X starts as the parent state s
-#pragma unroll
-            for (int ct = 0; ct < NC; ct++) {
-#pragma unroll
-                for (int rt = 0; rt < NRCW; rt++) {
-                    float y[16];
-#pragma unroll
-                    for (int i = 0; i < 16; i++) y[i] = X[rt][ct][i];
-                    img_store(img, RS0, k[ct].col, c.wr * NRCW + rt, c.h, y);
-                }
-                // ConcatInputsBlock: the one-hot action planes as channels C .. C+a-1 (padded to 16)
-                if (c.wr == 0) {
-                    const int cell = c.meta[3 * MAXNB + (k[ct].valid ? k[ct].board : 0)];
-                    float y[8];
-#pragma unroll
-                    for (int i = 0; i < 8; i++) {
-                        const int pl = 8 * c.h + i;
-                        y[i] = (k[ct].live && pl < d.a && cell == pl * HW + k[ct].p) ? 1.f : 0.f;
-                    }
-                    *reinterpret_cast<bf16x8*>(img + k[ct].col * RS0 + (C + 8 * c.h) * 2) = pack8(&y[0]);
-                }
-            }
-        }
-        conv_lds<G, KS0, 9, G::NRC, NRCW, RS0>(c, k, ring, X, b0 < b1 ? BS::open0 : 0, b0 < b1 ? BS::open1 : 0);
-    }
-
     {
         const u32x4* gbase = tw.gb;
         for (int blk = b0; blk < b1; blk++)
@@ -908,6 +839,86 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_seg(NetDims d, TowerDev tw, H
         }
     }
     STAMP_PRINT(c, "seg+rescale");
+}
+
+// ---- [conv0] + bottleneck blocks b0..b1-1 + [rescale, heads] -----------------------------------
+template <class G, int IN, int OUT>
+__global__ __launch_bounds__(G::NT, G::WPE) void k_seg(NetDims d, TowerDev tw, HeadDev hd, NetIO io, LdsPlan L, int NB, int b0,
+                                            int b1) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int C = G::C, NRCW = G::NRCW, NC = G::NC;
+    constexpr int CIN0 = IN == IN_OBS ? 32 : C + 16;  // input channels of conv0, padded to 16
+    constexpr int KS0 = CIN0 / 16;
+    constexpr int RS0 = CIN0 * 2 + 16;
+    using BS = BlockStages<G>;
+    Ctx c;
+    ctx_init<G>(c, smem, L, d, NB);
+    Col k[NC];
+    if (!setup<IN, NC>(d, io, NB, c, k)) return;
+    const int HW = d.HW;
+    const int g0 = blockIdx.x * NB;
+    char* img = smem + L.img_off;
+
+    WRing<G::NW, G::SM> ring;
+    f32x16 X[NRCW][NC];
+    if (IN == IN_X) {
+        ring.init(tw.stream + (long long)tw.foff[b0] * 64, smem + L.ring_off, c.wave, c.lane);
+        if (b0 < b1) {
+            ring.issue(BS::open0);
+            ring.issue(BS::open1);
+        }
+        x_load<NRCW, NC>(c, k, io.pool, 1, C, X);
+        STAMP(c, ST_XLOAD);
+    } else {
+        ring.init(tw.stream, smem + L.ring_off, c.wave, c.lane);
+        static_assert(num_stages(9 * KS0, G::NRC, G::SM) >= 2, "conv0 spans at least two stages");
+        ring.issue(stage_frags(9 * KS0, G::NRC, G::SM, 0));
+        ring.issue(stage_frags(9 * KS0, G::NRC, G::SM, 1));
+        // ---------------- input image + conv0 ----------------
+        if (IN == IN_OBS) {
+            zero_acc(X);
+            if (c.wr == 0) {
+#pragma unroll
+                for (int ct = 0; ct < NC; ct++) {
+                    const int g = g0 + (k[ct].valid ? k[ct].board : 0);
+                    float y[16];
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        const int ch = 16 * c.h + i;
+                        y[i] = (k[ct].live && ch < d.O) ? io.obs[((long long)g * d.O + ch) * HW + k[ct].p] : 0.f;
+                    }
+                    *reinterpret_cast<bf16x8*>(img + k[ct].col * RS0 + (16 * c.h) * 2) = pack8(&y[0]);
+                    *reinterpret_cast<bf16x8*>(img + k[ct].col * RS0 + (16 * c.h + 8) * 2) = pack8(&y[8]);
+                }
+            }
+        } else {
+            x_load<NRCW, NC>(c, k, io.pool, 0, C, X);   // StartResidualBlock: X starts as the parent state s
+#pragma unroll
+            for (int ct = 0; ct < NC; ct++) {
+#pragma unroll
+                for (int rt = 0; rt < NRCW; rt++) {
+                    float y[16];
+#pragma unroll
+                    for (int i = 0; i < 16; i++) y[i] = X[rt][ct][i];
+                    img_store(img, RS0, k[ct].col, c.wr * NRCW + rt, c.h, y);
+                }
+                // ConcatInputsBlock: the one-hot action planes as channels C .. C+a-1 (padded to 16)
+                if (c.wr == 0) {
+                    const int cell = c.meta[3 * MAXNB + (k[ct].valid ? k[ct].board : 0)];
+                    float y[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const int pl = 8 * c.h + i;
+                        y[i] = (k[ct].live && pl < d.a && cell == pl * HW + k[ct].p) ? 1.f : 0.f;
+                    }
+                    *reinterpret_cast<bf16x8*>(img + k[ct].col * RS0 + (C + 8 * c.h) * 2) = pack8(&y[0]);
+                }
+            }
+        }
+        conv_lds<G, KS0, 9, G::NRC, NRCW, RS0>(c, k, ring, X, b0 < b1 ? BS::open0 : 0, b0 < b1 ? BS::open1 : 0);
+    }
+
+    seg_rest<G, OUT>(c, k, d, tw, hd, io, L, smem, ring, X, NB, b0, b1);
 }
 
 // ---- PredictionBlock (B/c_mainfunctions/PredictionBlock.java:46-84) ------------------------------
@@ -1060,18 +1071,17 @@ size_t heads_lds_bytes(const NetDims& d) {
 // LDS: [image, C channels][region 2]; region 2 is the weight ring while c1 and c2 run and the
 // transposed image TB[channel][board*KP + cell] while the broadcast linear runs.
 // KSB = k-steps of the broadcast linear (cells padded to 16*KSB); its weight fragments stay in registers.
+// Body of the broadcast block: loads X from the destination slots, leaves x + block(x) in X.  nx0 / nx1 = the two ring
+// stages that follow the block's last conv (the next bottleneck block's opening stages when a fused kernel goes on).
 template <class G, int KSB>
-__global__ __launch_bounds__(G::NT, G::WPE) void k_bcast(NetDims d, TowerDev tw, NetIO io, LdsPlan L, int NB, int blk) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void bcast_body(Ctx& c, const Col (&k)[G::NC], const TowerDev& tw, const NetIO& io, const LdsPlan& L,
+                                           char* smem, WRing<G::NW, G::SM>& ring, f32x16 (&X)[G::NRCW][G::NC], int NB, int blk,
+                                           int nx0, int nx1) {
     constexpr int C = G::C, NRC = G::NRC, NRCW = G::NRCW, NC = G::NC;
     constexpr int QT = (KSB + 1) / 2, KP = 16 * KSB;
     constexpr int RS = C * 2 + 16;
     constexpr int KSC = C / 16;
     constexpr int FS0 = stage_frags(KSC, NRC, G::SM, 0), FS1 = stage_frags(KSC, NRC, G::SM, 1);
-    Ctx c;
-    ctx_init<G>(c, smem, L, d, NB);
-    Col k[NC];
-    if (!setup<IN_X, NC>(d, io, NB, c, k)) return;
     const long long e = c.HW + 1;
     const u32x4* gb1 = tw.gb + tw.gboff[blk];
     const u32x4* gb2 = gb1 + NRC * 8 * e;
@@ -1081,11 +1091,9 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_bcast(NetDims d, TowerDev tw,
     const int TBS = L.tbs;
     char* tb = smem + L.tb_off;
     char* img = smem + L.img_off;
-    WRing<G::NW, G::SM> ring;
     ring.init(tw.stream + (long long)tw.foff[blk] * 64, smem + L.ring_off, c.wave, c.lane);
     ring.issue(FS0);
     ring.issue(FS1);
-    f32x16 X[NRCW][NC];
     x_load<NRCW, NC>(c, k, io.pool, 1, C, X);
     {
         // LN1 -> image -> c1 (1x1, C -> C); this wave's share of the output rows stays in registers
@@ -1247,10 +1255,42 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_bcast(NetDims d, TowerDev tw,
     // c2: 1x1 conv C -> C on the image (own columns), accumulated into X
     ring.issue(FS0);
     ring.issue(FS1);
-    conv_lds<G, KSC, 1, NRC, NRCW, RS>(c, k, ring, X, 0, 0);
+    conv_lds<G, KSC, 1, NRC, NRCW, RS>(c, k, ring, X, nx0, nx1);
+}
+
+template <class G, int KSB>
+__global__ __launch_bounds__(G::NT, G::WPE) void k_bcast(NetDims d, TowerDev tw, NetIO io, LdsPlan L, int NB, int blk) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int C = G::C, NRCW = G::NRCW, NC = G::NC;
+    Ctx c;
+    ctx_init<G>(c, smem, L, d, NB);
+    Col k[NC];
+    if (!setup<IN_X, NC>(d, io, NB, c, k)) return;
+    WRing<G::NW, G::SM> ring;
+    f32x16 X[NRCW][NC];
+    bcast_body<G, KSB>(c, k, tw, io, L, smem, ring, X, NB, blk, 0, 0);
     x_store<NRCW, NC>(c, k, io.pool, C, X);
     STAMP(c, ST_XSTORE);
     STAMP_PRINT(c, "bcast");
+}
+
+// Broadcast block blk fused with the run of bottleneck blocks b0..b1-1 behind it (b0 = blk + 1) and that run's tail:
+// one X round trip through HBM and one launch boundary less than k_bcast + k_seg<IN_X>.  Runs on the broadcast
+// kernel's LDS plan (its image holds C channels, enough for the bottleneck images).
+template <class G, int KSB, int OUT>
+__global__ __launch_bounds__(G::NT, G::WPE) void k_bseg(NetDims d, TowerDev tw, HeadDev hd, NetIO io, LdsPlan L, int NB, int blk,
+                                             int b0, int b1) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NRCW = G::NRCW, NC = G::NC;
+    using BS = BlockStages<G>;
+    Ctx c;
+    ctx_init<G>(c, smem, L, d, NB);
+    Col k[NC];
+    if (!setup<IN_X, NC>(d, io, NB, c, k)) return;
+    WRing<G::NW, G::SM> ring;
+    f32x16 X[NRCW][NC];
+    bcast_body<G, KSB>(c, k, tw, io, L, smem, ring, X, NB, blk, b0 < b1 ? BS::open0 : 0, b0 < b1 ? BS::open1 : 0);
+    seg_rest<G, OUT>(c, k, d, tw, hd, io, L, smem, ring, X, NB, b0, b1);
 }
 
 // ------------------------------- host side: packing -------------------------------------------
@@ -1601,10 +1641,60 @@ void launch_bcast(MfmaNet* n, hipStream_t st, int grid, const NetDims& d, const 
     hipLaunchKernelGGL((k_bcast<G, KSB>), dim3(grid), dim3(G::NT), n->Lbc.total, st, d, tw, io, n->Lbc, n->NB, blk);
 }
 
+template <class G, int KSB, int OUT>
+void launch_bseg(MfmaNet* n, hipStream_t st, int grid, const NetDims& d, const TowerDev& tw, const NetIO& io, int blk, int b0,
+                 int b1) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bseg<G, KSB, OUT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_bseg<G, KSB, OUT>), dim3(grid), dim3(G::NT), n->Lbc.total, st, d, tw, n->hd, io, n->Lbc, n->NB,
+                       blk, b0, b1);
+}
+template <class G, int OUT>
+void launch_bseg_k(MfmaNet* n, hipStream_t st, int grid, const NetDims& d, const TowerDev& tw, const NetIO& io, int blk, int b0,
+                   int b1) {
+    switch (n->Lbc.kp / 16) {
+        case 1: launch_bseg<G, 1, OUT>(n, st, grid, d, tw, io, blk, b0, b1); break;
+        case 2: launch_bseg<G, 2, OUT>(n, st, grid, d, tw, io, blk, b0, b1); break;
+        case 3: launch_bseg<G, 3, OUT>(n, st, grid, d, tw, io, blk, b0, b1); break;
+        case 4: launch_bseg<G, 4, OUT>(n, st, grid, d, tw, io, blk, b0, b1); break;
+        case 5: launch_bseg<G, 5, OUT>(n, st, grid, d, tw, io, blk, b0, b1); break;
+        default: launch_bseg<G, 6, OUT>(n, st, grid, d, tw, io, blk, b0, b1); break;
+    }
+}
+
 template <class G>
 int forward_t(MfmaNet* n, hipStream_t st, bool initial, const NetDims& d, const NetIO& io) {
     const int grid = (io.B + n->NB - 1) / n->NB;
     const TowerDev& tw = n->tw[initial ? 0 : 1];
+    // MZ_FUSE=0: every broadcast block as its own launch (k_bcast) instead of fused with the blocks behind it (k_bseg)
+    static const bool fuse = !(std::getenv("MZ_FUSE") && std::atoi(std::getenv("MZ_FUSE")) == 0) &&
+                             !std::getenv("MZ_DEBUG_STOP");
+    if (fuse) {
+        int e = 0;
+        while (e < d.R && tw.type[e] == 0) e++;
+        bool last = e == d.R;
+        if (initial) {
+            if (last) launch_seg<G, IN_OBS, OUT_FINAL>(n, st, grid, d, tw, io, 0, e);
+            else launch_seg<G, IN_OBS, OUT_X>(n, st, grid, d, tw, io, 0, e);
+        } else {
+            if (last) launch_seg<G, IN_HIDDEN, OUT_FINAL>(n, st, grid, d, tw, io, 0, e);
+            else launch_seg<G, IN_HIDDEN, OUT_X>(n, st, grid, d, tw, io, 0, e);
+        }
+        while (!last) {
+            const int blk = e, b0 = e + 1;
+            e = b0;
+            while (e < d.R && tw.type[e] == 0) e++;
+            last = e == d.R;
+            if (last) launch_bseg_k<G, OUT_FINAL>(n, st, grid, d, tw, io, blk, b0, e);
+            else launch_bseg_k<G, OUT_X>(n, st, grid, d, tw, io, blk, b0, e);
+        }
+        hipLaunchKernelGGL(k_heads, dim3((io.B + HS - 1) / HS), dim3(HT), heads_lds_bytes(d), st, d, n->hd, io);
+        return 0;
+    }
     // runs of bottleneck blocks separated by broadcast blocks
     int b = 0;
     bool first = true;
