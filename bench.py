@@ -211,7 +211,7 @@ def main():
                        "games_per_gpu": B, "num_simulations": n, "parallelism": f"games sharded x{world}"},
             "roofline": {"bound": "mfma", "kernel": "recurrentInference", "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-                         "kernels": "k_seg(conv0+blocks) -> k_bcast -> k_seg(blocks+rescale) -> k_heads",
+                         "kernels": "k_tower(conv0 + blocks + broadcast block + blocks + rescale + head convs) -> k_heads",
                          "flops_per_launch": fl["recurrent"] * B, "avg_launch_ms": rec_ms / rec_n},
             "tree_kernels": {"bound": "hbm", "mean_path_len": mean_path, "algorithmic_bytes_per_sim": tree_bytes,
                              "achieved_GBps": (tree_bytes * sims_total / (tree_ms / 1e3) / 1e9) if tree_ms else None,

@@ -70,7 +70,7 @@ constexpr int ZROW_BYTES = 1024;
 enum { ST_STATS = 0, ST_NORM, ST_ACQ, ST_MMA, ST_XLOAD, ST_XSTORE, ST_RESCALE, ST_HEAD, ST_OTHER, ST_BCAST, ST_HCONV, ST_HLN, ST_HFC };
 
 enum { IN_OBS = 0, IN_HIDDEN = 1, IN_X = 2 };
-enum { OUT_X = 0, OUT_FINAL = 1 };
+enum { OUT_X = 0, OUT_FINAL = 1, OUT_REGS = 2 };   // OUT_REGS: X stays in registers (a fused kernel goes on)
 
 struct TowerDev {
     const u32x4* stream;   // A fragments in execution order
@@ -751,6 +751,7 @@ __device__ __forceinline__ void seg_rest(Ctx& c, const Col (&k)[G::NC], const Ne
         for (int blk = b0; blk < b1; blk++)
             bottleneck<G>(c, k, ring, gbase + tw.gboff[blk], X, blk + 1 < b1);
     }
+    if (OUT == OUT_REGS) return;
 
     if (OUT == OUT_X) {
         STAMP(c, ST_OTHER);
@@ -842,25 +843,20 @@ __device__ __forceinline__ void seg_rest(Ctx& c, const Col (&k)[G::NC], const Ne
 }
 
 // ---- [conv0] + bottleneck blocks b0..b1-1 + [rescale, heads] -----------------------------------
-template <class G, int IN, int OUT>
-__global__ __launch_bounds__(G::NT, G::WPE) void k_seg(NetDims d, TowerDev tw, HeadDev hd, NetIO io, LdsPlan L, int NB, int b0,
-                                            int b1) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// ---- front of a tower launch: the ring's first two stages, then X from the pool (IN_X) or the input image + conv0 ----
+template <class G, int IN>
+__device__ __forceinline__ void seg_front(Ctx& c, const Col (&k)[G::NC], const NetDims& d, const TowerDev& tw, const NetIO& io,
+                                          const LdsPlan& L, char* smem, WRing<G::NW, G::SM>& ring, f32x16 (&X)[G::NRCW][G::NC],
+                                          int NB, int b0, int b1) {
     constexpr int C = G::C, NRCW = G::NRCW, NC = G::NC;
     constexpr int CIN0 = IN == IN_OBS ? 32 : C + 16;  // input channels of conv0, padded to 16
     constexpr int KS0 = CIN0 / 16;
     constexpr int RS0 = CIN0 * 2 + 16;
     using BS = BlockStages<G>;
-    Ctx c;
-    ctx_init<G>(c, smem, L, d, NB);
-    Col k[NC];
-    if (!setup<IN, NC>(d, io, NB, c, k)) return;
     const int HW = d.HW;
     const int g0 = blockIdx.x * NB;
     char* img = smem + L.img_off;
 
-    WRing<G::NW, G::SM> ring;
-    f32x16 X[NRCW][NC];
     if (IN == IN_X) {
         ring.init(tw.stream + (long long)tw.foff[b0] * 64, smem + L.ring_off, c.wave, c.lane);
         if (b0 < b1) {
@@ -918,6 +914,20 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_seg(NetDims d, TowerDev tw, H
         conv_lds<G, KS0, 9, G::NRC, NRCW, RS0>(c, k, ring, X, b0 < b1 ? BS::open0 : 0, b0 < b1 ? BS::open1 : 0);
     }
 
+}
+
+template <class G, int IN, int OUT>
+__global__ __launch_bounds__(G::NT, G::WPE) void k_seg(NetDims d, TowerDev tw, HeadDev hd, NetIO io, LdsPlan L, int NB, int b0,
+                                            int b1) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NRCW = G::NRCW, NC = G::NC;
+    Ctx c;
+    ctx_init<G>(c, smem, L, d, NB);
+    Col k[NC];
+    if (!setup<IN, NC>(d, io, NB, c, k)) return;
+    WRing<G::NW, G::SM> ring;
+    f32x16 X[NRCW][NC];
+    seg_front<G, IN>(c, k, d, tw, io, L, smem, ring, X, NB, b0, b1);
     seg_rest<G, OUT>(c, k, d, tw, hd, io, L, smem, ring, X, NB, b0, b1);
 }
 
@@ -1071,9 +1081,10 @@ size_t heads_lds_bytes(const NetDims& d) {
 // LDS: [image, C channels][region 2]; region 2 is the weight ring while c1 and c2 run and the
 // transposed image TB[channel][board*KP + cell] while the broadcast linear runs.
 // KSB = k-steps of the broadcast linear (cells padded to 16*KSB); its weight fragments stay in registers.
-// Body of the broadcast block: loads X from the destination slots, leaves x + block(x) in X.  nx0 / nx1 = the two ring
-// stages that follow the block's last conv (the next bottleneck block's opening stages when a fused kernel goes on).
-template <class G, int KSB>
+// Body of the broadcast block: takes X from the destination slots (XREGS: from the registers of the blocks in front of
+// it in the same kernel, parking it in the destination slots meanwhile), leaves x + block(x) in X.  nx0 / nx1 = the two
+// ring stages that follow the block's last conv (the next bottleneck block's opening stages when the kernel goes on).
+template <class G, int KSB, bool XREGS = false>
 __device__ __forceinline__ void bcast_body(Ctx& c, const Col (&k)[G::NC], const TowerDev& tw, const NetIO& io, const LdsPlan& L,
                                            char* smem, WRing<G::NW, G::SM>& ring, f32x16 (&X)[G::NRCW][G::NC], int NB, int blk,
                                            int nx0, int nx1) {
@@ -1091,10 +1102,14 @@ __device__ __forceinline__ void bcast_body(Ctx& c, const Col (&k)[G::NC], const 
     const int TBS = L.tbs;
     char* tb = smem + L.tb_off;
     char* img = smem + L.img_off;
+    if (XREGS) lds_barrier();   // every wave has left the ring slots of the blocks in front before they are refilled
     ring.init(tw.stream + (long long)tw.foff[blk] * 64, smem + L.ring_off, c.wave, c.lane);
     ring.issue(FS0);
     ring.issue(FS1);
-    x_load<NRCW, NC>(c, k, io.pool, 1, C, X);
+    // X is dead between LN1 and c2 and the registers are needed in between: it waits in the sample's destination slot
+    // (the same lanes read back what they wrote; the ring's vmcnt(0) waits lie in between)
+    if (XREGS) x_store<NRCW, NC>(c, k, io.pool, C, X);
+    else x_load<NRCW, NC>(c, k, io.pool, 1, C, X);
     {
         // LN1 -> image -> c1 (1x1, C -> C); this wave's share of the output rows stays in registers
         f32x16 a[NRCW][NC];
@@ -1277,6 +1292,28 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_bcast(NetDims d, TowerDev tw,
 // Broadcast block blk fused with the run of bottleneck blocks b0..b1-1 behind it (b0 = blk + 1) and that run's tail:
 // one X round trip through HBM and one launch boundary less than k_bcast + k_seg<IN_X>.  Runs on the broadcast
 // kernel's LDS plan (its image holds C channels, enough for the bottleneck images).
+// The whole tower in one launch when it holds one broadcast block (Go): conv0 + blocks 0..blk-1 + broadcast block blk +
+// blocks blk+1..R-1 + tail.  X never travels between launches; it is parked in the destination slot only across the
+// middle of the broadcast block.
+template <class G, int IN, int KSB, int OUT>
+__global__ __launch_bounds__(G::NT, G::WPE) void k_tower(NetDims d, TowerDev tw, HeadDev hd, NetIO io, LdsPlan L, int NB, int blk,
+                                              int b1) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NRCW = G::NRCW, NC = G::NC;
+    using BS = BlockStages<G>;
+    Ctx c;
+    ctx_init<G>(c, smem, L, d, NB);
+    Col k[NC];
+    if (!setup<IN, NC>(d, io, NB, c, k)) return;
+    WRing<G::NW, G::SM> ring;
+    f32x16 X[NRCW][NC];
+    seg_front<G, IN>(c, k, d, tw, io, L, smem, ring, X, NB, 0, blk);
+    seg_rest<G, OUT_REGS>(c, k, d, tw, hd, io, L, smem, ring, X, NB, 0, blk);
+    const int b0 = blk + 1;
+    bcast_body<G, KSB, true>(c, k, tw, io, L, smem, ring, X, NB, blk, b0 < b1 ? BS::open0 : 0, b0 < b1 ? BS::open1 : 0);
+    seg_rest<G, OUT>(c, k, d, tw, hd, io, L, smem, ring, X, NB, b0, b1);
+}
+
 template <class G, int KSB, int OUT>
 __global__ __launch_bounds__(G::NT, G::WPE) void k_bseg(NetDims d, TowerDev tw, HeadDev hd, NetIO io, LdsPlan L, int NB, int blk,
                                              int b0, int b1) {
@@ -1365,7 +1402,7 @@ struct TowerHost {
 struct MfmaNet {
     NetDims d{};
     int geom = 0, NB = 0, WR = 1, NW = 8, SM = 32, NC = 1, COLS = 256;
-    LdsPlan Lseg{}, Lbc{};
+    LdsPlan Lseg{}, Lbc{}, Ltw{};   // k_seg, k_bcast / k_bseg, k_tower
     void* bufs[16] = {nullptr};
     int nbufs = 0;
     float* hfeat = nullptr;   // [max_batch][3][HW]
@@ -1408,9 +1445,9 @@ LdsPlan make_plan_seg(const NetDims& d, int COLS, int NW, int SM) {
     return L;
 }
 // k_bcast: [region 2 = ring / TB][image, C channels]
-LdsPlan make_plan_bcast(const NetDims& d, int COLS, int NB, int NW, int SM) {
+LdsPlan make_plan_bcast(const NetDims& d, int COLS, int NB, int NW, int SM, bool with_conv0 = false) {
     LdsPlan L{};
-    const int rsc = d.C * 2 + 16;
+    const int rsc = with_conv0 ? (d.C + 16) * 2 + 16 : d.C * 2 + 16;
     L.kp = (d.HW + 15) / 16 * 16;
     L.qt = (d.HW + 31) / 32;
     L.tbs = (NB * L.kp + 8) * 2;
@@ -1477,6 +1514,7 @@ MfmaNet* mfma_create(const NetDims& d, int max_batch, std::string* err) {
     }
     n->Lseg = make_plan_seg(d, n->COLS, n->NW, n->SM);
     n->Lbc = make_plan_bcast(d, n->COLS, n->NB, n->NW, n->SM);
+    n->Ltw = make_plan_bcast(d, n->COLS, n->NB, n->NW, n->SM, true);
     const int bc_items = n->NB * (d.C / 32) * n->Lbc.qt;
     const bool has_bcast = d.bcast_every_n > 0 && d.R >= d.bcast_every_n;
     if (n->Lseg.total > 160 * 1024 || (has_bcast && (n->Lbc.total > 160 * 1024 || bc_items > 256))) {
@@ -1653,6 +1691,33 @@ void launch_bseg(MfmaNet* n, hipStream_t st, int grid, const NetDims& d, const T
     hipLaunchKernelGGL((k_bseg<G, KSB, OUT>), dim3(grid), dim3(G::NT), n->Lbc.total, st, d, tw, n->hd, io, n->Lbc, n->NB,
                        blk, b0, b1);
 }
+template <class G, int IN, int KSB>
+void launch_tower(MfmaNet* n, hipStream_t st, int grid, const NetDims& d, const TowerDev& tw, const NetIO& io, int blk) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower<G, IN, KSB, OUT_FINAL>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_tower<G, IN, KSB, OUT_FINAL>), dim3(grid), dim3(G::NT), n->Ltw.total, st, d, tw, n->hd, io, n->Ltw,
+                       n->NB, blk, d.R);
+}
+// one launch for towers with a single broadcast block on the board sizes of the reference's games (k-step counts 2, 4, 6
+// of the broadcast linear: 25-, 49- and 81-cell boards) and the two-waves-per-SIMD geometries; false: not this shape
+template <class G, int IN>
+bool try_launch_tower(MfmaNet* n, hipStream_t st, int grid, const NetDims& d, const TowerDev& tw, const NetIO& io, int blk) {
+    if constexpr (G::NC != 1) {
+        return false;
+    } else {
+        if (n->Ltw.total > 160 * 1024) return false;
+        switch (n->Lbc.kp / 16) {
+            case 2: launch_tower<G, IN, 2>(n, st, grid, d, tw, io, blk); return true;
+            case 4: launch_tower<G, IN, 4>(n, st, grid, d, tw, io, blk); return true;
+            case 6: launch_tower<G, IN, 6>(n, st, grid, d, tw, io, blk); return true;
+            default: return false;
+        }
+    }
+}
 template <class G, int OUT>
 void launch_bseg_k(MfmaNet* n, hipStream_t st, int grid, const NetDims& d, const TowerDev& tw, const NetIO& io, int blk, int b0,
                    int b1) {
@@ -1670,13 +1735,25 @@ template <class G>
 int forward_t(MfmaNet* n, hipStream_t st, bool initial, const NetDims& d, const NetIO& io) {
     const int grid = (io.B + n->NB - 1) / n->NB;
     const TowerDev& tw = n->tw[initial ? 0 : 1];
-    // MZ_FUSE=0: every broadcast block as its own launch (k_bcast) instead of fused with the blocks behind it (k_bseg)
+    // MZ_FUSE=0: every broadcast block as its own launch (k_bcast); MZ_FUSE=1: fused with the blocks behind it (k_bseg);
+    // default: that, and the whole tower as one launch (k_tower) where it holds a single broadcast block
     static const bool fuse = !(std::getenv("MZ_FUSE") && std::atoi(std::getenv("MZ_FUSE")) == 0) &&
                              !std::getenv("MZ_DEBUG_STOP");
     if (fuse) {
         int e = 0;
         while (e < d.R && tw.type[e] == 0) e++;
         bool last = e == d.R;
+        if (!last) {   // exactly one broadcast block: the whole tower as one launch
+            int e2 = e + 1;
+            while (e2 < d.R && tw.type[e2] == 0) e2++;
+            static const bool tower = !(std::getenv("MZ_FUSE") && std::atoi(std::getenv("MZ_FUSE")) == 1);
+            if (tower && e2 == d.R &&
+                (initial ? try_launch_tower<G, IN_OBS>(n, st, grid, d, tw, io, e)
+                         : try_launch_tower<G, IN_HIDDEN>(n, st, grid, d, tw, io, e))) {
+                hipLaunchKernelGGL(k_heads, dim3((io.B + HS - 1) / HS), dim3(HT), heads_lds_bytes(d), st, d, n->hd, io);
+                return 0;
+            }
+        }
         if (initial) {
             if (last) launch_seg<G, IN_OBS, OUT_FINAL>(n, st, grid, d, tw, io, 0, e);
             else launch_seg<G, IN_OBS, OUT_X>(n, st, grid, d, tw, io, 0, e);
