@@ -28,7 +28,7 @@ for i in (1, 2, 3, 4, 5):
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
             disp[k].add(r["Dispatch_Id"])
     for k, v in sorted(agg.items()):
-        if "k_seg" in k or "k_bcast" in k or "k_heads" in k:
+        if any(t in k for t in ("k_seg", "k_bcast", "k_bseg", "k_tower", "k_heads")):
             n = len(disp[k])
             print(f"{k:46s} dispatches {n:3d}  " + "  ".join(f"{a}={b / n:.4g}" for a, b in sorted(v.items())))
 PY
