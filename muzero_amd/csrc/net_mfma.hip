@@ -1106,10 +1106,7 @@ __device__ __forceinline__ void bcast_body(Ctx& c, const Col (&k)[G::NC], const 
     ring.init(tw.stream + (long long)tw.foff[blk] * 64, smem + L.ring_off, c.wave, c.lane);
     ring.issue(FS0);
     ring.issue(FS1);
-    // X is dead between LN1 and c2 and the registers are needed in between: it waits in the sample's destination slot
-    // (the same lanes read back what they wrote; the ring's vmcnt(0) waits lie in between)
-    if (XREGS) x_store<NRCW, NC>(c, k, io.pool, C, X);
-    else x_load<NRCW, NC>(c, k, io.pool, 1, C, X);
+    if (!XREGS) x_load<NRCW, NC>(c, k, io.pool, 1, C, X);   // XREGS: X simply stays in its registers through the block
     {
         // LN1 -> image -> c1 (1x1, C -> C); this wave's share of the output rows stays in registers
         f32x16 a[NRCW][NC];
@@ -1167,9 +1164,9 @@ __device__ __forceinline__ void bcast_body(Ctx& c, const Col (&k)[G::NC], const 
     float* ipart = c.wpart + 2 * MAXNB * G::NW * 2;   // [items][2]
     float* bstat = ipart + 2 * 256;                   // [MAXNB][2]
     const int nitems = NB * NRC;
-    // the residual stream for c2 is requested here (it was not held in registers through c1 and the transpose), so
-    // its round trip runs under the two passes
-    x_load<NRCW, NC>(c, k, io.pool, 1, C, X);
+    // separate launch: the residual stream for c2 is requested here (it was not held in registers through c1 and the
+    // transpose), so its round trip runs under the two passes
+    if (!XREGS) x_load<NRCW, NC>(c, k, io.pool, 1, C, X);
     // gamma/beta of LN3 for (row tile rtw, cells q): 4 x 16-byte loads, requested one (item, q tile) ahead in pass 1
     auto g3_load = [&](int it, int qt, u32x4(&g)[4]) {
         if (it >= nitems) return;

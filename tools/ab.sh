@@ -4,6 +4,6 @@ g=$1; shift
 for round in 1 2; do
   for lib in "$@"; do
     echo -n "$(basename $lib): "
-    MZ_LIB=$PWD/$lib timeout -k 10 120 python3 tools/bench_net.py --games $g --iters 20 || exit 1
+    MZ_LIB=$PWD/$lib timeout -k 10 120 python3 tools/bench_net.py --games $g --iters 20 $ABX || exit 1
   done
 done
