@@ -1402,6 +1402,7 @@ struct MfmaNet {
     LdsPlan Lseg{}, Lbc{}, Ltw{};   // k_seg, k_bcast / k_bseg, k_tower
     void* bufs[16] = {nullptr};
     int nbufs = 0;
+    int fuse = 2;             // launch chain: 0 k_seg -> k_bcast -> k_seg, 1 k_seg -> k_bseg, 2 k_tower where instantiated
     float* hfeat = nullptr;   // [max_batch][3][HW]
     int max_batch = 0;
     TowerDev tw[2]{};
@@ -1519,6 +1520,9 @@ MfmaNet* mfma_create(const NetDims& d, int max_batch, std::string* err) {
         delete n;
         return nullptr;
     }
+    // MZ_FUSE (read when the context is created): the launch chain, see forward_t; MZ_DEBUG_STOP needs the unfused one
+    if (const char* e = std::getenv("MZ_FUSE")) n->fuse = std::atoi(e);
+    if (std::getenv("MZ_DEBUG_STOP")) n->fuse = 0;
     n->max_batch = max_batch > 0 ? max_batch : 1;
     if (hipMalloc(reinterpret_cast<void**>(&n->hfeat), (size_t)n->max_batch * 3 * d.HW * sizeof(float)) != hipSuccess) {
         if (err) *err = "hipMalloc failed in mfma_create";
@@ -1734,8 +1738,7 @@ int forward_t(MfmaNet* n, hipStream_t st, bool initial, const NetDims& d, const 
     const TowerDev& tw = n->tw[initial ? 0 : 1];
     // MZ_FUSE=0: every broadcast block as its own launch (k_bcast); MZ_FUSE=1: fused with the blocks behind it (k_bseg);
     // default: that, and the whole tower as one launch (k_tower) where it holds a single broadcast block
-    static const bool fuse = !(std::getenv("MZ_FUSE") && std::atoi(std::getenv("MZ_FUSE")) == 0) &&
-                             !std::getenv("MZ_DEBUG_STOP");
+    const bool fuse = n->fuse != 0;
     if (fuse) {
         int e = 0;
         while (e < d.R && tw.type[e] == 0) e++;
@@ -1743,7 +1746,7 @@ int forward_t(MfmaNet* n, hipStream_t st, bool initial, const NetDims& d, const 
         if (!last) {   // exactly one broadcast block: the whole tower as one launch
             int e2 = e + 1;
             while (e2 < d.R && tw.type[e2] == 0) e2++;
-            static const bool tower = !(std::getenv("MZ_FUSE") && std::atoi(std::getenv("MZ_FUSE")) == 1);
+            const bool tower = n->fuse >= 2;
             if (tower && e2 == d.R &&
                 (initial ? try_launch_tower<G, IN_OBS>(n, st, grid, d, tw, io, e)
                          : try_launch_tower<G, IN_HIDDEN>(n, st, grid, d, tw, io, e))) {

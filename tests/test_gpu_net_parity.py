@@ -110,6 +110,18 @@ def test_bf16_mfma_forward_matches_oracle(name):
     _check(_specs()[name], capi.PRECISION_BF16, B=7, seed=3)
 
 
+@pytest.mark.parametrize("env,name", [({"MZ_FUSE": "0"}, "go9"), ({"MZ_FUSE": "1"}, "go9"),
+                                      ({"MZ_FUSE": "0"}, "pegsolitair"), ({"MZ_FUSE": "1"}, "go5"),
+                                      ({"MZ_GEOM": "1"}, "go9"), ({"MZ_GEOM": "1", "MZ_FUSE": "0"}, "pegsolitair")])
+def test_bf16_alternative_launch_chains_and_geometry(env, name, monkeypatch):
+    """The diagnostic variants kept for A/B runs meet the same tolerance: separate k_seg / k_bcast
+    launches (MZ_FUSE=0), broadcast block fused with the blocks behind it (MZ_FUSE=1; the default is the one-launch
+    tower), and 4 waves x 2 column tiles per workgroup (MZ_GEOM=1).  Both are read when the context is created."""
+    for key, val in env.items():
+        monkeypatch.setenv(key, val)
+    _check(_specs()[name], capi.PRECISION_BF16, B=7, seed=4)
+
+
 def test_bf16_mfma_matches_fp32_path_statistically():
     """Same weights through both HIP paths: the bf16 error stays at the bf16 rounding level."""
     spec = netspec.spec_go9()
