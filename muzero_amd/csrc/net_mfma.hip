@@ -21,16 +21,20 @@
 //     registers) into a three-slot ring, two stages ahead; a slot holds one stage (<= 24 fragments) that
 //     all 8 waves read with ds_read_b128.  One barrier per stage publishes the slot that was requested
 //     two stages ago and frees the one just computed for the next prefetch.
-//   * The prediction heads (tiny fp32 latency chains) run in their own kernel, one small workgroup per
-//     sample at high occupancy, off the hidden state the tower has just written.
+//   * On single-row wave grids the 1x1 convs of a bottleneck block skip the image: the LayerNorm output, packed in
+//     accumulator order, IS the B operand (ln_to_regs / conv_regs; A fragments packed in the matching k order).
+//   * The prediction heads: their three 1x1 convs are taken off X in registers by the tower's last launch (3 floats per
+//     cell to HeadDev::hfeat); the rest (tiny fp32 latency chains) runs in its own kernel, one small workgroup per four
+//     samples at high occupancy.
 //   * LayerNorm over (C,H,W) of a sample = per-lane partial sums -> masked DPP butterfly per board ->
 //     per-wave partials in LDS -> one barrier -> per-board mean / rstd.  ReLU, residual add, min-max
 //     rescale, softmax and the value scaling are fused too.
-// A tower runs as 1..3 launches: [conv0 + bottleneck blocks] -> [broadcast block] -> [bottleneck
-// blocks + rescale + heads]; between launches X travels through the sample's own destination
-// hidden-state slot, which is overwritten at the end anyway.
-// HBM traffic per sample: parent hidden state in, child hidden state out (+ X round trips at the
-// broadcast block), logits/policy/value out.
+// Launches per tower (MfmaNet::fuse, MZ_FUSE): a tower with one broadcast block (Go) is ONE kernel, k_tower = conv0 +
+// bottleneck blocks + broadcast block + bottleneck blocks + rescale + head convs, X in registers from end to end; towers
+// with several broadcast blocks run k_seg -> k_bseg (broadcast block + the blocks behind it) -> ..., X travelling through
+// the sample's own destination hidden-state slot (overwritten at the end anyway); towers with none one k_seg.  k_heads
+// follows.  HBM traffic per sample on the one-kernel path: parent hidden state in, child hidden state out,
+// logits/policy/value out.
 //
 // Reference math: see net_fp32.hip / oracle/net.py (same citations).
 #include "net_mfma.h"
