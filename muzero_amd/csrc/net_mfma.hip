@@ -250,7 +250,9 @@ __device__ __forceinline__ float wave_red(float v) {
 // value; (2) lanes < NB publish wpart[parity][board][wave] (neutral where the wave holds none of the
 // board), barrier, and every lane combines the eight wave partials of its own board.  wpart alternates
 // between two buffers so the next reduction's writes cannot overtake this one's reads.
-template <int MODE, int NW, int NC>
+// VM: the barrier also waits for this wave's vector-memory operations (LDS-DMA of a gamma/beta table that the other waves
+// are about to read).
+template <int MODE, int NW, int NC, bool VM = false>
 __device__ __forceinline__ void board_reduce(Ctx& c, const Col (&k)[NC], float (&a)[NC], float (&b)[NC], float n_inv) {
     const float na = MODE == 0 ? 0.f : INFINITY, nb = MODE == 0 ? 0.f : -INFINITY;
     const int bmin = (32 * NC * c.wc) / c.HW;
@@ -285,7 +287,8 @@ __device__ __forceinline__ void board_reduce(Ctx& c, const Col (&k)[NC], float (
     float* wp = c.wpart + c.parity * (MAXNB * NW * 2);
     c.parity ^= 1;
     if (c.lane < c.NB) *reinterpret_cast<f32x2*>(wp + (c.lane * NW + c.wave) * 2) = (f32x2){ma, mb};
-    lds_barrier();
+    if (VM) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else lds_barrier();
 #pragma unroll
     for (int ct = 0; ct < NC; ct++) {
         const int bd = k[ct].board < MAXNB ? k[ct].board : 0;
@@ -315,7 +318,7 @@ __device__ __forceinline__ void board_reduce(Ctx& c, const Col (&k)[NC], float (
 }
 
 // LayerNorm statistics of this wave's NR row tiles x own column -> per-column (mean, rstd) of the board.
-template <int NR, int NW, int NC>
+template <int NR, int NW, int NC, bool VM = false>
 __device__ __forceinline__ void ln_stats(Ctx& c, const Col (&k)[NC], const f32x16 (&v)[NR][NC], int nch, float (&mean)[NC],
                                          float (&rstd)[NC]) {
 #pragma unroll
@@ -332,7 +335,7 @@ __device__ __forceinline__ void ln_stats(Ctx& c, const Col (&k)[NC], const f32x1
         mean[ct] = k[ct].valid ? s2.x + s2.y : 0.f;
         rstd[ct] = k[ct].valid ? q2.x + q2.y : 0.f;
     }
-    board_reduce<0, NW, NC>(c, k, mean, rstd, 1.0f / (float)(nch * c.HW));
+    board_reduce<0, NW, NC, VM>(c, k, mean, rstd, 1.0f / (float)(nch * c.HW));
 }
 
 // gamma/beta of global row tile rt for this lane's (cell, channels): 4 x 16-byte loads.
@@ -344,6 +347,27 @@ __device__ __forceinline__ void gb_load(const u32x4* gb, Ctx& c, const Col& k, i
     for (int qd = 0; qd < 4; qd++)
         g[qd] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(gb) + off + qd * stride);
     __builtin_amdgcn_sched_barrier(0x38F);  // keep the loads here (everything but VMEM may cross)
+}
+
+// The same entries from a copy of the table in LDS (gtab_issue).
+__device__ __forceinline__ void gb_load_lds(const char* gtab, Ctx& c, const Col& k, int rt, u32x4 (&g)[4]) {
+    const unsigned stride = (unsigned)(c.HW + 1) * 32u;
+    const unsigned off = (unsigned)(c.h * (c.HW + 1) + k.pz) * 16u + (unsigned)(rt * 4) * stride;
+#pragma unroll
+    for (int qd = 0; qd < 4; qd++) g[qd] = *reinterpret_cast<const u32x4*>(gtab + off + qd * stride);
+}
+// One LayerNorm's gamma/beta table (bytes, contiguous) global -> LDS by LDS-DMA in 1 KiB pieces dealt to the waves: the three
+// boards of a workgroup then share one fetch of it, and the lanes read it with ds_read_b128 while the LDS is idle anyway.
+// The copy runs under a conv; the LayerNorm's statistics barrier (board_reduce<.., VM>) publishes it.
+template <int NW>
+__device__ __forceinline__ void gtab_issue(Ctx& c, const u32x4* table, int bytes, char* gtab) {
+    const unsigned dst = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)gtab;
+    const int npieces = (bytes + 1023) >> 10;
+    for (int f = c.wave; f < npieces; f += NW) {
+        const char* gp = reinterpret_cast<const char*>(table) + (size_t)f * 1024 + c.lane * 16;
+        const unsigned m0v = dst + f * 1024;
+        asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp), "s"(m0v) : "memory");
+    }
 }
 
 // y = relu((v - mean) * rstd * gamma + beta) for the 16 accumulator rows of one row tile.
@@ -398,24 +422,30 @@ __device__ __forceinline__ void img_store(char* img, int rs, int col, int rt, in
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
 // relu(LN(v)) of this wave's NR row tiles -> image rows of its own columns.  gb = this LayerNorm's table.
-template <int NR, int NW, int NC>
+// gtab != nullptr: the table was copied to LDS under the conv in front (gtab_issue) and is read from there.
+template <int NR, int NW, int NC, bool LDSG = false>
 __device__ __forceinline__ void ln_to_image(Ctx& c, const Col (&k)[NC], const u32x4* gb, const f32x16 (&v)[NR][NC], int nch,
-                                            int rs) {
+                                            int rs, const char* gtab = nullptr) {
     char* img = c.smem + c.L.img_off;
     u32x4 g[NR][NC][4];
     // the first two row tiles are requested before the statistics round trip, the rest right after it
+    if (!LDSG) {
 #pragma unroll
-    for (int rt = 0; rt < (NR < 2 ? NR : 2); rt++)
+        for (int rt = 0; rt < (NR < 2 ? NR : 2); rt++)
 #pragma unroll
-        for (int ct = 0; ct < NC; ct++) gb_load(gb, c, k[ct], c.wr * NR + rt, g[rt][ct]);
+            for (int ct = 0; ct < NC; ct++) gb_load(gb, c, k[ct], c.wr * NR + rt, g[rt][ct]);
+    }
     float mean[NC], rstd[NC];
     STAMP(c, ST_OTHER);
-    ln_stats<NR, NW, NC>(c, k, v, nch, mean, rstd);
+    ln_stats<NR, NW, NC, LDSG>(c, k, v, nch, mean, rstd);
     STAMP(c, ST_STATS);
 #pragma unroll
-    for (int rt = 2; rt < NR; rt++)
+    for (int rt = (LDSG ? 0 : 2); rt < NR; rt++)
 #pragma unroll
-        for (int ct = 0; ct < NC; ct++) gb_load(gb, c, k[ct], c.wr * NR + rt, g[rt][ct]);
+        for (int ct = 0; ct < NC; ct++) {
+            if (LDSG) gb_load_lds(gtab, c, k[ct], c.wr * NR + rt, g[rt][ct]);
+            else gb_load(gb, c, k[ct], c.wr * NR + rt, g[rt][ct]);
+        }
 #pragma unroll
     for (int rt = 0; rt < NR; rt++)
 #pragma unroll
@@ -431,9 +461,14 @@ __device__ __forceinline__ void ln_to_image(Ctx& c, const Col (&k)[NC], const u3
 // Stream order of the layer's fragments: (tap, ks, ro) with natural k.  The first two stages of the stream from
 // here on must already be in flight; after1 / after2 = the two stages that follow this conv's last (0: nothing).
 // LDS reads per MFMA = (NROW + NC) / (NROW * NC): the A fragments are shared by the wave's column tiles.
-template <class G, int KS, int TAPS, int NROT, int NROW, int RS>
+struct NoHook {
+    __device__ __forceinline__ void operator()() const {}
+};
+// hook: called once, right after the first stage's barrier and DMA issue (every wave has left the LayerNorm in front of
+// this conv by then, and loads requested here do not sit in front of that barrier's vmcnt(0))
+template <class G, int KS, int TAPS, int NROT, int NROW, int RS, class Hook = NoHook>
 __device__ __forceinline__ void conv_lds(Ctx& c, const Col (&k)[G::NC], WRing<G::NW, G::SM>& ring,
-                                         f32x16 (&acc)[NROW][G::NC], int after1, int after2) {
+                                         f32x16 (&acc)[NROW][G::NC], int after1, int after2, Hook hook = Hook()) {
     constexpr int NC = G::NC;
     constexpr int KK = TAPS * KS;
     constexpr int SK = stage_ksteps(KK, NROT, G::SM);
@@ -476,6 +511,7 @@ __device__ __forceinline__ void conv_lds(Ctx& c, const Col (&k)[G::NC], WRing<G:
             STAMP(c, ST_ACQ);
             const int j = kk / SK + 2;   // the stage requested now
             ring.issue(j < NST ? stage_frags(KK, NROT, G::SM, j) : (j == NST ? after1 : after2));
+            if (kk == 0) hook();
             load_ops(kk, slot, ocur);
         }
         const bool more = kk + 1 < KK && (kk + 1) % SK != 0;
@@ -496,22 +532,27 @@ __device__ __forceinline__ void conv_lds(Ctx& c, const Col (&k)[G::NC], WRing<G:
 // in that order they are the B operands of two k-steps whose k index runs k = 8h + j <-> channel
 // 32rt + 16s + 4h + (j & 3) + 8(j >> 2) (s = k-step parity) - the order pack_conv_kperm gives the A fragments.
 // No LDS image, no ds_write, no B reads for the 1x1 convs.
-template <int NR, int NW, int NC>
+template <int NR, int NW, int NC, bool LDSG = false>
 __device__ __forceinline__ void ln_to_regs(Ctx& c, const Col (&k)[NC], const u32x4* gb, const f32x16 (&v)[NR][NC], int nch,
-                                           u32x4 (&bop)[2 * NR][NC]) {
+                                           u32x4 (&bop)[2 * NR][NC], const char* gtab = nullptr) {
     u32x4 g[NR][NC][4];
+    if (!LDSG) {
 #pragma unroll
-    for (int rt = 0; rt < (NR < 2 ? NR : 2); rt++)
+        for (int rt = 0; rt < (NR < 2 ? NR : 2); rt++)
 #pragma unroll
-        for (int ct = 0; ct < NC; ct++) gb_load(gb, c, k[ct], rt, g[rt][ct]);
+            for (int ct = 0; ct < NC; ct++) gb_load(gb, c, k[ct], rt, g[rt][ct]);
+    }
     float mean[NC], rstd[NC];
     STAMP(c, ST_OTHER);
-    ln_stats<NR, NW, NC>(c, k, v, nch, mean, rstd);
+    ln_stats<NR, NW, NC, LDSG>(c, k, v, nch, mean, rstd);
     STAMP(c, ST_STATS);
 #pragma unroll
-    for (int rt = 2; rt < NR; rt++)
+    for (int rt = (LDSG ? 0 : 2); rt < NR; rt++)
 #pragma unroll
-        for (int ct = 0; ct < NC; ct++) gb_load(gb, c, k[ct], rt, g[rt][ct]);
+        for (int ct = 0; ct < NC; ct++) {
+            if (LDSG) gb_load_lds(gtab, c, k[ct], rt, g[rt][ct]);
+            else gb_load(gb, c, k[ct], rt, g[rt][ct]);
+        }
 #pragma unroll
     for (int rt = 0; rt < NR; rt++)
 #pragma unroll
@@ -526,9 +567,9 @@ __device__ __forceinline__ void ln_to_regs(Ctx& c, const Col (&k)[NC], const u32
 
 // acc[ro][ct] += W * bop for a 1x1 conv whose B operands are in registers (KS k-steps, fragments (ks, ro) in k-permuted
 // order); same ring protocol as conv_lds.
-template <class G, int KS, int NROT>
+template <class G, int KS, int NROT, class Hook = NoHook>
 __device__ __forceinline__ void conv_regs(Ctx& c, WRing<G::NW, G::SM>& ring, const u32x4 (&bop)[KS][G::NC],
-                                          f32x16 (&acc)[NROT][G::NC], int after1, int after2) {
+                                          f32x16 (&acc)[NROT][G::NC], int after1, int after2, Hook hook = Hook()) {
     constexpr int NC = G::NC;
     constexpr int SK = stage_ksteps(KS, NROT, G::SM);
     constexpr int NST = num_stages(KS, NROT, G::SM);
@@ -547,6 +588,7 @@ __device__ __forceinline__ void conv_regs(Ctx& c, WRing<G::NW, G::SM>& ring, con
             STAMP(c, ST_ACQ);
             const int j = kk / SK + 2;
             ring.issue(j < NST ? stage_frags(KS, NROT, G::SM, j) : (j == NST ? after1 : after2));
+            if (kk == 0) hook();
             load_a(kk, acur);
         }
         const bool more = kk + 1 < KS && (kk + 1) % SK != 0;
@@ -604,13 +646,21 @@ __device__ __forceinline__ void bottleneck(Ctx& c, const Col (&k)[G::NC], WRing<
     const u32x4* gb3 = gb2 + G::NRB * 8 * e;
     const u32x4* gb4 = gb3 + G::NRB * 8 * e;
     f32x16 a1[G::NRBW][G::NC];
+    // Single-row wave grids: the tables of LN2, LN3, LN4 are copied to LDS under the conv in front of each, behind the
+    // bottleneck image (which the register-fed 1x1 convs leave to the 3x3 convs alone).
+    constexpr bool LG = G::WR == 1;
+    char* gtab = c.smem + c.L.img_off + (G::COLS * RSB + 1023) / 1024 * 1024;
+    const int gbytes = G::NRB * 8 * (int)e * 16;
+    auto cp2 = [&]() { gtab_issue<G::NW>(c, gb2, gbytes, gtab); };
+    auto cp3 = [&]() { if (LG) gtab_issue<G::NW>(c, gb3, gbytes, gtab); };
+    auto cp4 = [&]() { if (LG) gtab_issue<G::NW>(c, gb4, gbytes, gtab); };
 
     // LN1 -> c1 (1x1, C -> CB): B operands from registers when the wave holds all channels, else through the image
     if constexpr (G::WR == 1) {
         u32x4 bop[KSC][G::NC];
         ln_to_regs<G::NRC, G::NW, G::NC>(c, k, gb1, X, C, bop);
         zero_acc(a1);
-        conv_regs<G, KSC, G::NRB>(c, ring, bop, a1, BS::c2(0), BS::c2(1));
+        conv_regs<G, KSC, G::NRB>(c, ring, bop, a1, BS::c2(0), BS::c2(1), cp2);
     } else {
         ln_to_image<G::NRCW, G::NW, G::NC>(c, k, gb1, X, C, RSC);
         zero_acc(a1);
@@ -619,15 +669,17 @@ __device__ __forceinline__ void bottleneck(Ctx& c, const Col (&k)[G::NC], WRing<
     // LN2 -> image -> c2 (3x3), LN3 -> image -> c3 (3x3); the image is consumed before a1 is rewritten
 #pragma unroll
     for (int layer = 0; layer < 2; layer++) {
-        ln_to_image<G::NRBW, G::NW, G::NC>(c, k, layer == 0 ? gb2 : gb3, a1, CB, RSB);
+        ln_to_image<G::NRBW, G::NW, G::NC, LG>(c, k, layer == 0 ? gb2 : gb3, a1, CB, RSB, gtab);
         zero_acc(a1);
-        conv_lds<G, KSB, 9, G::NRB, G::NRBW, RSB>(c, k, ring, a1, layer == 0 ? BS::c2(0) : BS::c4(0),
-                                                  layer == 0 ? BS::c2(1) : (BS::n4 > 1 ? BS::c4(1) : nx0));
+        if (layer == 0)
+            conv_lds<G, KSB, 9, G::NRB, G::NRBW, RSB>(c, k, ring, a1, BS::c2(0), BS::c2(1), cp3);
+        else
+            conv_lds<G, KSB, 9, G::NRB, G::NRBW, RSB>(c, k, ring, a1, BS::c4(0), BS::n4 > 1 ? BS::c4(1) : nx0, cp4);
     }
     // LN4 -> c4 (1x1, CB -> C) accumulated into X
     if constexpr (G::WR == 1) {
         u32x4 bop[KSB][G::NC];
-        ln_to_regs<G::NRB, G::NW, G::NC>(c, k, gb4, a1, CB, bop);
+        ln_to_regs<G::NRB, G::NW, G::NC, true>(c, k, gb4, a1, CB, bop, gtab);
         conv_regs<G, KSB, G::NRC>(c, ring, bop, X, nx0, nx1);
     } else {
         ln_to_image<G::NRBW, G::NW, G::NC>(c, k, gb4, a1, CB, RSB);
@@ -1623,7 +1675,7 @@ int mfma_pack_weights(MfmaNet* n, const NetDims& d, const float* blob, size_t co
         const void* p;
         if (upload(n, th[t].stream, &p, 1024, err)) return -1;
         th[t].dev.stream = (const u32x4*)p;
-        if (upload(n, th[t].gb, &p, 64, err)) return -1;
+        if (upload(n, th[t].gb, &p, 2048, err)) return -1;   // gtab_issue copies whole KiB pieces
         th[t].dev.gb = (const u32x4*)p;
         if (upload(n, th[t].wbf, &p, 64, err)) return -1;
         th[t].dev.wbf = (const u32x4*)p;
