@@ -189,7 +189,7 @@ def main():
         # HBM traffic of the dominant launch: PMC numbers (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 passes) are
         # collected offline by tools/pmc.sh and committed per sample; bench.py scales them to this run's batch.
         traffic = None
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r1h_traffic_{args.workload}.json")
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r1i_traffic_{args.workload}.json")
         if args.precision == "bf16" and os.path.exists(tpath):
             with open(tpath) as f:
                 traffic = json.load(f)["bytes_per_sample"] * B
