@@ -4,9 +4,11 @@
 One "step" = one planned move for every game of the batch through the C ABI (mz_search_moves):
 initialInference of all roots, root expansion + Gumbel top-m, then n x [select -> recurrentInference
 of all leaves -> expand/backup/sequential halving], then storeSearchStatistics + selectAction.
-Inputs (observations, legal masks, Gumbel noise) and outputs are resident in HBM during the timed
-region.  Games shard over GPUs (one process per GPU, no data-path collective); RCCL only broadcasts
-the weight blob before the timed region and gathers the per-rank statistics after it.
+Inputs (observations, legal masks) and outputs are resident in HBM during the timed region; the Gumbel
+noise is drawn on the device (Philox, seed 7 - SURVEY.md §8d).  Games shard over GPUs (one process per
+GPU, no data-path collective); RCCL - through the C ABI, mz_comm_init / mz_broadcast_weights /
+mz_gather_stats - only broadcasts the weight blob before the timed region and gathers the per-rank
+statistics after it; torch.distributed only hands rank 0's RCCL id to the other ranks.
 
   python bench.py --gpus 1 --steps 3 --warmup 1
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -85,6 +87,34 @@ def cpu_baseline(spec, weights, n, m, c_visit, bounds, games, seed, max_batch=10
     return sims / dt, sims, dt, torch.get_num_threads()
 
 
+def find_traffic(workload, precision, games):
+    """HBM bytes per launch of the dominant kernel chain from the PMC passes of tools/pmc.sh (FETCH_SIZE and WRITE_SIZE
+    in separate rocprofv3 --pmc runs, gfx950 correction applied there).  Picks the newest committed
+    profiles/*traffic_<workload>*.json of this precision, preferring one measured at this batch; a figure measured at
+    another batch is scaled per sample and says so.  None (and a loud note on stderr) if there is none."""
+    import glob
+    best = None
+    for path in glob.glob(os.path.join(ROOT, "profiles", f"*traffic_{workload}*.json")):
+        try:
+            with open(path) as f:
+                t = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if t.get("precision") != precision or "bytes_per_sample" not in t:
+            continue
+        key = (t.get("games") == games, os.path.basename(path))
+        if best is None or key > best[0]:
+            best = (key, path, t)
+    if best is None:
+        print(f"[bench] no profiles/*traffic_{workload}*.json for {precision}: roofline.traffic is null "
+              "(run tools/pmc.sh on the GPU box and commit its traffic json)", file=sys.stderr, flush=True)
+        return None, None
+    _, path, t = best
+    src = os.path.relpath(path, ROOT) + (f" (measured at {t.get('games')} games, scaled per sample)"
+                                         if t.get("games") != games else f" (measured at {games} games)")
+    return t["bytes_per_sample"] * games, src
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -98,7 +128,6 @@ def main():
     args = ap.parse_args()
 
     import torch
-    import torch.distributed as dist
     from muzero_amd import capi, netspec
     from muzero_amd import dist as mzd
 
@@ -107,25 +136,34 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    mzd.init("nccl", dev)
 
     spec_name, n, m, c_visit, bounds = WORKLOADS[args.workload]
     spec = netspec.SPECS[spec_name]()
     B, A = args.games, spec.action_space
     precision = capi.PRECISION_BF16 if args.precision == "bf16" else capi.PRECISION_FP32
-    ctx = capi.Context(capi.make_config(spec, n, m, c_visit, known_bounds=bounds, max_games=B, precision=precision),
+    ctx = capi.Context(capi.make_config(spec, n, m, c_visit, known_bounds=bounds, max_games=B, precision=precision,
+                                        gumbel_seed=7 + 1000003 * rank),   # a stream of its own per shard
                        device=local_rank)
     ctx.set_action_cells(netspec.action_cells_board(spec))
 
-    # weights: rank 0 draws them, RCCL broadcasts the blob over xGMI, every rank repacks locally
+    # weights: rank 0 draws them, RCCL broadcasts the fp32 blob over xGMI into every context's master copy,
+    # every other rank repacks locally (mz_broadcast_weights)
     weights = netspec.random_weights(spec, seed=1) if rank == 0 or world == 1 else None
-    if world > 1:
-        wt = mzd.blob_tensor(spec, weights, dev)
-        mzd.broadcast_weights(wt, src=0)
-        torch.cuda.synchronize()
-        ctx.load_weights(wt)
-    else:
+    if weights is not None:
         ctx.load_weights(netspec.pack_blob(spec, weights))
+    comm = None
+    if world > 1:
+        try:
+            comm = mzd.NativeComm(ctx, rank, world)
+            comm.broadcast_weights(0)
+        except Exception as e:   # noqa: BLE001 - keep the scaling run alive and say what carried the collectives
+            print(f"[bench] native RCCL communicator failed on rank {rank}: {e}; falling back to torch.distributed",
+                  file=sys.stderr, flush=True)
+            comm = mzd.HostComm("nccl", dev)
+            wt = comm.blob_tensor(spec, weights)
+            comm.broadcast_weights(wt, root=0)
+            torch.cuda.synchronize()
+            ctx.load_weights(wt)
 
     # synthetic games: random 0/1 planes of density 0.3, all actions legal, device Gumbel noise
     gen = torch.Generator(device=dev)
@@ -139,21 +177,17 @@ def main():
                 sims_run=torch.zeros(B, dtype=torch.int32, device=dev),
                 status=torch.zeros(B, dtype=torch.int32, device=dev))
 
-    def draw_gumbel():
-        u = torch.rand((B, A), generator=gen, device=dev, dtype=torch.float64).clamp_(1e-300, 1.0 - 1e-16)
-        return -torch.log(-torch.log(u))
-
     def sync():
         ctx.synchronize()
         torch.cuda.synchronize()
-        mzd.barrier()
+        if comm is not None:
+            comm.barrier()
 
-    def step(g):
-        ctx.search_moves(B, obs, legal, gumbel=g, outputs=outs)
+    def step():
+        ctx.search_moves(B, obs, legal, outputs=outs)   # gumbel=None + device_gumbel: k_root draws the noise
 
     for _ in range(args.warmup):
-        step(draw_gumbel())
-    noise = [draw_gumbel() for _ in range(args.steps)]
+        step()
     ctx.set_timing(True)
     sims_total = 0
     kernel_ms = {k: 0.0 for k in capi.T_NAMES}
@@ -162,7 +196,7 @@ def main():
     sync()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step(noise[k])
+        step()
         s, mp = ctx.last_stats()
         sims_total += s
         path_sum += mp * s
@@ -174,8 +208,11 @@ def main():
     assert int(outs["status"].abs().sum().item()) == 0
 
     # whole-job aggregate: MAX time over ranks, SUM of simulations (episode statistics gathered over RCCL)
-    dt = mzd.max_over_ranks(dt, dev)
-    sims_all = int(mzd.gather_stats([sims_total], dev)[:, 0].sum())
+    if comm is not None:
+        dt = comm.max_over_ranks(dt)
+        sims_all = int(comm.gather_stats([sims_total])[:, 0].sum())
+    else:
+        sims_all = sims_total
 
     if rank == 0:
         fl = netspec.flops_per_sample(spec)
@@ -188,11 +225,7 @@ def main():
         tree_ms = kernel_ms["tree_select"] + kernel_ms["tree_backup"]
         # HBM traffic of the dominant launch: PMC numbers (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 passes) are
         # collected offline by tools/pmc.sh and committed per sample; bench.py scales them to this run's batch.
-        traffic = None
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r1i_traffic_{args.workload}.json")
-        if args.precision == "bf16" and os.path.exists(tpath):
-            with open(tpath) as f:
-                traffic = json.load(f)["bytes_per_sample"] * B
+        traffic, traffic_src = find_traffic(args.workload, args.precision, B)
         line = {
             "metric": "MCTS simulations/sec",
             "value": sims_all / dt,
@@ -208,9 +241,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.workload} self-play search, {B} concurrent games per GPU, "
                                    f"n={n} simulations, m={m}, C={spec.channels}, R={spec.residuals}",
-                       "games_per_gpu": B, "num_simulations": n, "parallelism": f"games sharded x{world}"},
+                       "games_per_gpu": B, "num_simulations": n, "parallelism": f"games sharded x{world}",
+                       "gumbel": "device Philox4x32-10", "collectives": comm.kind if comm is not None else None},
             "roofline": {"bound": "mfma", "kernel": "recurrentInference", "achieved": achieved, "peak": peak,
-                         "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+                         "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
                          "kernels": "k_tower(conv0 + blocks + broadcast block + blocks + rescale + head convs) -> k_heads",
                          "flops_per_launch": fl["recurrent"] * B, "avg_launch_ms": rec_ms / rec_n},
             "tree_kernels": {"bound": "hbm", "mean_path_len": mean_path, "algorithmic_bytes_per_sim": tree_bytes,
@@ -225,9 +259,9 @@ def main():
                                     "sample": f"{args.cpu_games} games x 1 move ({sims} simulations, {secs:.1f} s): "
                                               "oracle search + fp32 torch-CPU forward, lock-step batches <= 1000"}
         print(json.dumps(line), flush=True)
+    if comm is not None:
+        comm.close()
     ctx.close()
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -54,6 +54,13 @@ typedef struct mz_search_config {
     double bound_min, bound_max;
     double root_exploration_fraction; /* rootExplorationFraction (Dirichlet noise is an input) */
     double temperature_root;          /* temperatureRoot */
+    /* withGumbel=true with the noise drawn ON THE DEVICE (GumbelFunctions.drawGumble, GumbelFunctions.java:48-54;
+     * GumbelSearch.gumbelActionsStart, GumbelSearch.java:126-151): when device_gumbel != 0 and mz_search_moves gets
+     * gumbel == NULL, k_root draws g = -log(-log(u)) per legal child from Philox4x32-10 keyed by gumbel_seed and
+     * counted by (move counter, game, action).  device_gumbel == 0 keeps NULL = withGumbel=false. */
+    uint64_t gumbel_seed;
+    int32_t device_gumbel;
+    int32_t reserved0;
 } mz_search_config;
 
 enum { MZ_PRECISION_FP32 = 0, MZ_PRECISION_BF16 = 1 };
@@ -108,12 +115,33 @@ size_t mz_num_params(const mz_ctx* ctx);
 int mz_weights_device_ptr(mz_ctx* ctx, void** ptr, size_t* bytes);
 int mz_commit_weights(mz_ctx* ctx);
 
+/* ---- multi-GPU: one context per GPU, RCCL over xGMI (BASELINE.json north_star) ----------
+ * The reference is single-device (ModelController.java:121,136), so these have no counterpart there; they carry
+ * what north_star names: weights broadcast from the training rank after each epoch, episode statistics gathered.
+ * librccl.so.1 is opened on the first call (dlopen), so the library loads on hosts without RCCL.
+ *   mz_comm_unique_id   rank 0 fills id[MZ_COMM_ID_BYTES] (ncclGetUniqueId) and hands it to the other ranks by any
+ *                       host channel (file, socket, JVM-side rendezvous).
+ *   mz_comm_init        ncclCommInitRank on the context's device; collective: every rank calls it.
+ *   mz_broadcast_weights  ncclBroadcast of the fp32 master blob (mz_weights_device_ptr) from `root`, in place,
+ *                       then the local repack of mz_commit_weights.  The root must have loaded its weights.
+ *   mz_gather_stats     ncclAllGather of n doubles per rank: out[r*n + i] = rank r's in[i] (host or device pointers).
+ *   mz_comm_barrier     all ranks have reached this call and their streams have drained. */
+#define MZ_COMM_ID_BYTES 128
+int mz_comm_unique_id(void* id /* [MZ_COMM_ID_BYTES] */);
+int mz_comm_init(mz_ctx* ctx, const void* id /* [MZ_COMM_ID_BYTES] */, int rank, int world);
+int mz_comm_destroy(mz_ctx* ctx);
+int mz_broadcast_weights(mz_ctx* ctx, int root);
+int mz_gather_stats(mz_ctx* ctx, const double* in /* [n] */, int n, double* out /* [world*n] */);
+int mz_comm_barrier(mz_ctx* ctx);
+
 /* ---- inference level: ModelService.initialInference(List<Game>) / recurrentInference ----------
  * (P/agent/d_model/service/ModelService.java:34-67,137-175; Network.java:172-231;
  *  NetworkIO.java:39-52).  Hidden states stay in HBM; `*_slot` are indices into the context's pool
  *  [0, pool_slots) and play the role of NetworkIO.hiddenState handles. */
 int mz_initial_inference(mz_ctx* ctx, int B, const float* obs /* [B*O*H*W] */, const int32_t* dst_slot /* [B] */,
                          float* logits /* [B*A] */, float* policy /* [B*A] */, double* value /* [B] */);
+/* Aliasing rule of mz_recurrent_inference (checked, error otherwise): the dst slots of one call are pairwise
+ * distinct, and dst_slot[i] == src_slot[j] is allowed only for i == j (a sample may overwrite its own parent). */
 int mz_recurrent_inference(mz_ctx* ctx, int B, const int32_t* src_slot, const int32_t* action,
                            const int32_t* dst_slot, float* logits, float* policy, double* value);
 int mz_read_hidden(mz_ctx* ctx, int32_t slot, float* out /* [C*H*W] */);
@@ -125,11 +153,14 @@ int mz_read_hidden(mz_ctx* ctx, int32_t slot, float* out /* [C*H*W] */);
  *  legal            [B*A]      last entry of GameDTO.legalActions (Game.legalActions, Game.java:165-174)
  *  to_play          [B]        0/1, Game.toPlay (NULL = 0)
  *  num_simulations  [B]        config.getNumSimulations(game) (MuZeroConfig.java:343-362); NULL = default
- *  gumbel           [B*A]      g per ACTION index (GumbelFunctions.drawGumble); NULL = withGumbel=false
+ *  gumbel           [B*A]      g per ACTION index (GumbelFunctions.drawGumble); NULL = withGumbel=false, or, with
+ *                              search.device_gumbel set, noise drawn on the device (read back: mz_get_gumbel)
  *  dirichlet        [B*A]      Dirichlet sample per ACTION index (Functions.numpyRandomDirichlet);
  *                              NULL => no noise even if root_exploration_fraction != 0
  *  exploration_time [B]        Game.isItExplorationTime (Game.java:501-507); NULL = 0
- *  u                [B]        uniform draw of Functions.draw (Functions.java:128-138); NULL = 0 */
+ *  u                [B]        uniform draw of Functions.draw (Functions.java:128-138); must not be NULL when the
+ *                              configured mode can draw (non-HYBRID without gumbel_action_selection; HYBRID without
+ *                              gumbel_action_selection or with exploration_time given): error otherwise */
 int mz_search_moves(mz_ctx* ctx, int B, const float* obs, const uint8_t* legal, const uint8_t* to_play,
                     const int32_t* num_simulations, const double* gumbel, const double* dirichlet,
                     const uint8_t* exploration_time, const double* u, const mz_move_outputs* out);
@@ -144,10 +175,23 @@ int mz_search_moves_injected(mz_ctx* ctx, int B, const uint8_t* legal, const uin
                              const uint8_t* exploration_time, const double* u, const mz_move_outputs* out);
 
 /* Record the network outputs mz_search_moves uses, so a CPU replay can check the search bit for bit.
- * After a recorded call: init_* as above, sim_* sized [B*S*A] / [B*S] with S = max_simulations. */
+ * After a recorded call of B games: init_* [B*A] / [B], sim_* [B*S*A] / [B*S] with S = max_simulations and B = the
+ * B of that recorded call (mz_get_recording copies exactly that many games; *B_out, if not NULL, receives it). */
 int mz_set_recording(mz_ctx* ctx, int enable);
 int mz_get_recording(mz_ctx* ctx, float* init_logits, float* init_policy, double* init_value, float* sim_logits,
                      float* sim_policy, double* sim_value);
+int mz_get_recording_games(mz_ctx* ctx);
+/* Gumbel noise the last mz_search_moves* call used, by ACTION index, [B*A] for that call's B (0 for illegal actions
+ * and for games that took the one-legal-action shortcut): lets a CPU replay follow a device-drawn search. */
+int mz_get_gumbel(mz_ctx* ctx, double* gumbel /* [B*A] */);
+/* Reposition the device Gumbel stream: seed and the move counter the next mz_search_moves call uses (it then
+ * advances by one per call).  Same seed + same counter + same game index => same noise. */
+int mz_seed_gumbel(mz_ctx* ctx, uint64_t seed, uint64_t move_counter);
+/* Child order of a root with the given legal mask = iteration order of the reference's HashMap<Action, Node>
+ * (Node.java:295-304): order[j] = action index of child j, returns the number of children L.  Node.addExplorationNoise
+ * applies noise[j] to child j (Node.java:353-358); mz_search_moves takes Dirichlet noise by ACTION index, so a
+ * recorded reference noise vector n is replayed as dirichlet[order[j]] = n[j].  Pure host function, ctx may be NULL. */
+int mz_child_order(const uint8_t* legal /* [A] */, int A, int32_t* order /* [A] */);
 
 /* ---- introspection: Game.getSearchManager().getRoot() / Node getters (GumbelSearch.java:37,
  * Node.java:48-78; used by renderers TicTacToeGame.java:192-206, GoGame.java:186-204) --------------

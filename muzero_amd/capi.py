@@ -30,7 +30,8 @@ class SearchConfig(C.Structure):
                 ("known_bounds", C.c_int32), ("hybrid", C.c_int32), ("gumbel_action_selection", C.c_int32),
                 ("c_scale", C.c_double), ("discount", C.c_double), ("bound_min", C.c_double),
                 ("bound_max", C.c_double), ("root_exploration_fraction", C.c_double),
-                ("temperature_root", C.c_double)]
+                ("temperature_root", C.c_double), ("gumbel_seed", C.c_uint64), ("device_gumbel", C.c_int32),
+                ("reserved0", C.c_int32)]
 
 
 class Config(C.Structure):
@@ -50,7 +51,10 @@ EXPORTS = (
     "mz_weights_device_ptr", "mz_commit_weights", "mz_initial_inference", "mz_recurrent_inference",
     "mz_read_hidden", "mz_search_moves", "mz_search_moves_injected", "mz_set_recording", "mz_get_recording",
     "mz_tree_num_nodes", "mz_tree_node", "mz_tree_minmax", "mz_set_timing", "mz_get_timing", "mz_get_last_stats",
-    "mz_synchronize", "mz_version")
+    "mz_synchronize", "mz_version", "mz_comm_unique_id", "mz_comm_init", "mz_comm_destroy", "mz_broadcast_weights",
+    "mz_gather_stats", "mz_comm_barrier", "mz_get_recording_games", "mz_get_gumbel", "mz_seed_gumbel",
+    "mz_child_order")
+COMM_ID_BYTES = 128
 
 _lib = None
 
@@ -89,8 +93,36 @@ def lib():
         L.mz_get_last_stats.argtypes = [vp, vp, vp]
         L.mz_synchronize.argtypes = [vp]
         L.mz_version.restype = C.c_char_p
+        L.mz_comm_unique_id.argtypes = [vp]
+        L.mz_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
+        L.mz_comm_destroy.argtypes = [vp]
+        L.mz_broadcast_weights.argtypes = [vp, C.c_int]
+        L.mz_gather_stats.argtypes = [vp, vp, C.c_int, vp]
+        L.mz_comm_barrier.argtypes = [vp]
+        L.mz_get_recording_games.argtypes = [vp]
+        L.mz_get_gumbel.argtypes = [vp, vp]
+        L.mz_seed_gumbel.argtypes = [vp, C.c_uint64, C.c_uint64]
+        L.mz_child_order.argtypes = [vp, C.c_int, vp]
         _lib = L
     return _lib
+
+
+def comm_unique_id():
+    """ncclGetUniqueId through the C ABI: rank 0 calls it and hands the 128 bytes to the other ranks."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    if lib().mz_comm_unique_id(C.cast(buf, C.c_void_p)) != 0:
+        raise MuZeroError(lib().mz_last_error(None).decode())
+    return buf.raw
+
+
+def child_order(legal):
+    """Root child order (HashMap iteration order of the legal actions, Node.java:295-304) -> action indices."""
+    legal = np.ascontiguousarray(legal, np.uint8)
+    order = np.empty(legal.size, np.int32)
+    L = lib().mz_child_order(_ptr(legal), legal.size, _ptr(order))
+    if L < 0:
+        raise MuZeroError("mz_child_order failed")
+    return order[:L].copy()
 
 
 class MuZeroError(RuntimeError):
@@ -120,7 +152,7 @@ def _np(a, dtype):
 
 def make_config(spec, num_simulations, initial_gumbel_m, c_visit, c_scale=1.0, discount=1.0, known_bounds=None,
                 root_exploration_fraction=0.0, hybrid=False, gumbel_action_selection=True, temperature_root=1.0,
-                max_games=1, max_simulations=None, precision=PRECISION_FP32, pool_slots=0):
+                max_games=1, max_simulations=None, precision=PRECISION_FP32, pool_slots=0, gumbel_seed=None):
     cfg = Config()
     n = cfg.net
     n.height, n.width = spec.height, spec.width
@@ -138,6 +170,8 @@ def make_config(spec, num_simulations, initial_gumbel_m, c_visit, c_scale=1.0, d
     s.bound_min, s.bound_max = (0.0, 0.0) if known_bounds is None else known_bounds
     s.root_exploration_fraction = root_exploration_fraction
     s.temperature_root = temperature_root
+    s.device_gumbel = 0 if gumbel_seed is None else 1   # gumbel=None then means: draw the noise on the device
+    s.gumbel_seed = 0 if gumbel_seed is None else gumbel_seed
     cfg.max_games = max_games
     cfg.max_simulations = max_simulations if max_simulations is not None else num_simulations
     cfg.precision = precision
@@ -275,7 +309,7 @@ class Context:
         self._check(lib().mz_set_recording(self._h, 1 if enable else 0))
 
     def get_recording(self):
-        B, A, S = self.cfg.max_games, self.A, self.cfg.max_simulations
+        B, A, S = lib().mz_get_recording_games(self._h), self.A, self.cfg.max_simulations
         r = dict(init_logits=np.empty((B, A), np.float32), init_policy=np.empty((B, A), np.float32),
                  init_value=np.empty(B, np.float64), sim_logits=np.empty((B, S, A), np.float32),
                  sim_policy=np.empty((B, S, A), np.float32), sim_value=np.empty((B, S), np.float64))
@@ -283,6 +317,36 @@ class Context:
                                            _ptr(r["init_value"]), _ptr(r["sim_logits"]), _ptr(r["sim_policy"]),
                                            _ptr(r["sim_value"])))
         return r
+
+    def get_gumbel(self, B):
+        """Gumbel noise (by action index) the last search of B games used - drawn on the device or passed in."""
+        g = np.empty((B, self.A), np.float64)
+        self._check(lib().mz_get_gumbel(self._h, _ptr(g)))
+        return g
+
+    def seed_gumbel(self, seed, move_counter=0):
+        self._check(lib().mz_seed_gumbel(self._h, seed, move_counter))
+
+    # --- multi-GPU (RCCL through the C ABI) -------------------------------------------------------
+    def comm_init(self, unique_id, rank, world):
+        assert len(unique_id) == COMM_ID_BYTES
+        buf = C.create_string_buffer(bytes(unique_id), COMM_ID_BYTES)
+        self._check(lib().mz_comm_init(self._h, C.cast(buf, C.c_void_p), rank, world))
+
+    def comm_destroy(self):
+        self._check(lib().mz_comm_destroy(self._h))
+
+    def broadcast_weights(self, root=0):
+        self._check(lib().mz_broadcast_weights(self._h, root))
+
+    def gather_stats(self, values, world):
+        v = np.ascontiguousarray(values, np.float64)
+        out = np.empty((world, v.size), np.float64)
+        self._check(lib().mz_gather_stats(self._h, _ptr(v), v.size, _ptr(out)))
+        return out
+
+    def comm_barrier(self):
+        self._check(lib().mz_comm_barrier(self._h))
 
     # --- introspection ----------------------------------------------------------------------------
     def num_nodes(self, g):

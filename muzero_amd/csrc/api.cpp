@@ -2,12 +2,15 @@
 // chains the tree kernels and the inference kernels on one HIP stream, and the inference-level calls.
 #include "../../include/muzero_hip.h"
 
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>   // types and prototypes only: librccl is opened with dlopen on first use
 
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -70,7 +73,7 @@ struct mz_ctx {
     long long pool_total = 0;
 
     // per-step buffers
-    int *net_src = nullptr, *net_dst = nullptr, *net_action = nullptr, *net_active = nullptr, *any_active = nullptr;
+    int *net_src = nullptr, *net_dst = nullptr, *net_action = nullptr, *net_active = nullptr;
     float *net_logits = nullptr, *net_policy = nullptr;
     double* net_value = nullptr;
     unsigned long long* stats = nullptr;
@@ -82,6 +85,13 @@ struct mz_ctx {
     bool recording = false;
     Recording rec{};
     DevBuf rec_buf[6];
+    int rec_B = 0;                  // games of the last recorded call
+    int last_B = 0;                 // games of the last mz_search_moves* call (mz_get_gumbel)
+    unsigned long long gumbel_seed = 0, gumbel_move = 0;   // device Gumbel stream (mz_seed_gumbel)
+    void* comm = nullptr;           // ncclComm_t (mz_comm_init)
+    int comm_rank = 0, comm_world = 1;
+    double* comm_buf = nullptr;     // device staging of mz_gather_stats
+    size_t comm_buf_count = 0;
     // device outputs
     DeviceMoveOutputs dout{};
     // timing
@@ -233,6 +243,49 @@ void timing_end(mz_ctx* ctx) {
     }
 }
 
+// ---- RCCL, bound at run time ---------------------------------------------------------------------
+struct Rccl {
+    void* handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string error;
+};
+Rccl* rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // a copy already in the process (e.g. the one a host framework ships) is reused by its SONAME
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (r.handle) break;
+        }
+        if (!r.handle) {
+            r.error = std::string("dlopen(librccl.so.1) failed: ") + dlerror();
+            return;
+        }
+#define MZ_SYM(f)                                                        \
+    r.f = reinterpret_cast<decltype(r.f)>(dlsym(r.handle, "nccl" #f));   \
+    if (!r.f) r.error = "librccl lacks nccl" #f;
+        MZ_SYM(GetUniqueId)
+        MZ_SYM(CommInitRank)
+        MZ_SYM(CommDestroy)
+        MZ_SYM(Broadcast)
+        MZ_SYM(AllGather)
+        MZ_SYM(GetErrorString)
+#undef MZ_SYM
+    });
+    return &r;
+}
+#define NCCL_TRY(expr)                                                                                   \
+    do {                                                                                                 \
+        ncclResult_t r_ = (expr);                                                                        \
+        if (r_ != ncclSuccess) return ctx_fail(ctx, std::string(#expr) + ": " + rccl()->GetErrorString(r_)); \
+    } while (0)
+
 // ---- weight packing ---------------------------------------------------------------------------
 struct BlobWalker {
     const float* base;
@@ -380,7 +433,8 @@ int run_net(mz_ctx* ctx, bool initial, const NetIO& io) {
         std::string err;
         if (mfma_forward(ctx->mfma, ctx->stream, initial, ctx->nd, io, &err) != 0) return ctx_fail(ctx, err);
     } else {
-        launch_net_fp32(ctx->stream, initial, ctx->nd, ctx->prog_dev, ctx->w_f32, io);
+        if (hipError_t e = launch_net_fp32(ctx->stream, initial, ctx->nd, ctx->prog_dev, ctx->w_f32, io))
+            return ctx_fail(ctx, std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(e));
     }
     return 0;
 }
@@ -466,6 +520,13 @@ int search_impl(mz_ctx* ctx, int B, const float* obs, const uint8_t* legal, cons
     if (!legal) return ctx_fail(ctx, "legal must not be NULL");
     if (!injected && !ctx->weights_loaded) return ctx_fail(ctx, "weights not loaded");
     if (!injected && !obs) return ctx_fail(ctx, "obs must not be NULL");
+    {
+        // Functions.draw needs its uniform: with u == NULL the draw would silently return index 0, legal or not
+        const mz_search_config& sc = ctx->cfg.search;
+        const bool draws = sc.hybrid ? (!sc.gumbel_action_selection || exploration_time != nullptr)
+                                     : !sc.gumbel_action_selection;
+        if (draws && !u) return ctx_fail(ctx, "u must not be NULL: the configured selectAction mode draws an action");
+    }
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t A = ctx->nd.A;
     const NetDims& d = ctx->nd;
@@ -496,6 +557,12 @@ int search_impl(mz_ctx* ctx, int B, const float* obs, const uint8_t* legal, cons
 
     TreeParams P = ctx->tp;
     P.B = B;
+    P.device_gumbel = (!gumbel && ctx->cfg.search.device_gumbel) ? 1 : 0;
+    P.gumbel_seed = ctx->gumbel_seed;
+    P.gumbel_move = ctx->gumbel_move;
+    if (P.device_gumbel) ctx->gumbel_move++;
+    ctx->last_B = B;
+    if (ctx->recording) ctx->rec_B = B;
     StagedOutputs so;
     DeviceMoveOutputs dout;
     if (stage_move_outputs(ctx, B, out, so, dout)) return -1;
@@ -538,8 +605,7 @@ int search_impl(mz_ctx* ctx, int B, const float* obs, const uint8_t* legal, cons
     for (int s = 0; s < steps; s++) {
         {
             TimerScope ts(ctx, MZ_T_TREE_SELECT);
-            launch_select(ctx->stream, P, ctx->ts, ctx->net_src, ctx->net_dst, ctx->net_action, ctx->net_active,
-                          ctx->any_active);
+            launch_select(ctx->stream, P, ctx->ts, ctx->net_src, ctx->net_dst, ctx->net_action, ctx->net_active);
         }
         if (!injected) {
             NetIO io{};
@@ -651,6 +717,9 @@ int mz_create(const mz_config* cfg, int device, mz_ctx** out) {
     P.bmax = cfg->search.bound_max;
     P.frac = cfg->search.root_exploration_fraction;
     P.temp_root = cfg->search.temperature_root;
+    P.device_gumbel = 0;
+    P.gumbel_seed = P.gumbel_move = 0;
+    ctx->gumbel_seed = cfg->search.gumbel_seed;
 
     TreeStore& T = ctx->ts;
     const size_t BNA = B * N * A, BA = B * A, BN = B * N;
@@ -683,7 +752,7 @@ int mz_create(const mz_config* cfg, int device, mz_ctx** out) {
     if (dev_alloc(ctx, &ctx->pool, (size_t)ctx->pool_total * d.C * d.HW)) return fail("");
     const size_t Bio = std::max<size_t>(B, (size_t)std::max(0, cfg->pool_slots));
     if (dev_alloc(ctx, &ctx->net_src, Bio) || dev_alloc(ctx, &ctx->net_dst, Bio) || dev_alloc(ctx, &ctx->net_action, Bio) ||
-        dev_alloc(ctx, &ctx->net_active, Bio) || dev_alloc(ctx, &ctx->any_active, 1) ||
+        dev_alloc(ctx, &ctx->net_active, Bio) ||
         dev_alloc(ctx, &ctx->net_logits, Bio * A) || dev_alloc(ctx, &ctx->net_policy, Bio * A) ||
         dev_alloc(ctx, &ctx->net_value, Bio) || dev_alloc(ctx, &ctx->stats, 2))
         return fail("");
@@ -717,6 +786,8 @@ void mz_destroy(mz_ctx* ctx) {
         if (b.p) (void)hipFree(b.p);
     if (ctx->w_f32) (void)hipFree(ctx->w_f32);
     if (ctx->mfma) mfma_destroy(ctx->mfma);
+    if (ctx->comm) (void)rccl()->CommDestroy((ncclComm_t)ctx->comm);
+    if (ctx->comm_buf) (void)hipFree(ctx->comm_buf);
     for (auto& e : ctx->events) {
         (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
@@ -766,6 +837,93 @@ int mz_weights_device_ptr(mz_ctx* ctx, void** ptr, size_t* bytes) {
 int mz_commit_weights(mz_ctx* ctx) {
     if (!ctx) return -1;
     return mz_load_weights(ctx, ctx->w_master, ctx->n_params);
+}
+
+int mz_comm_unique_id(void* id) {
+    if (!id) return ctx_fail(nullptr, "null argument");
+    Rccl* R = rccl();
+    if (!R->error.empty()) return ctx_fail(nullptr, R->error);
+    static_assert(sizeof(ncclUniqueId) == MZ_COMM_ID_BYTES, "id size");
+    ncclUniqueId u;
+    ncclResult_t r = R->GetUniqueId(&u);
+    if (r != ncclSuccess) return ctx_fail(nullptr, std::string("ncclGetUniqueId: ") + R->GetErrorString(r));
+    std::memcpy(id, &u, sizeof(u));
+    return 0;
+}
+
+int mz_comm_init(mz_ctx* ctx, const void* id, int rank, int world) {
+    if (!ctx || !id) return ctx_fail(ctx, "null argument");
+    if (world < 1 || rank < 0 || rank >= world) return ctx_fail(ctx, "need 0 <= rank < world");
+    if (ctx->comm) return ctx_fail(ctx, "communicator already initialised");
+    Rccl* R = rccl();
+    if (!R->error.empty()) return ctx_fail(ctx, R->error);
+    HIP_TRY(hipSetDevice(ctx->device));
+    ncclUniqueId u;
+    std::memcpy(&u, id, sizeof(u));
+    ncclComm_t comm = nullptr;
+    NCCL_TRY(R->CommInitRank(&comm, world, u, rank));
+    ctx->comm = comm;
+    ctx->comm_rank = rank;
+    ctx->comm_world = world;
+    return 0;
+}
+
+int mz_comm_destroy(mz_ctx* ctx) {
+    if (!ctx) return -1;
+    if (!ctx->comm) return 0;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    ncclResult_t r = rccl()->CommDestroy((ncclComm_t)ctx->comm);
+    ctx->comm = nullptr;
+    if (ctx->comm_buf) (void)hipFree(ctx->comm_buf);
+    ctx->comm_buf = nullptr;
+    ctx->comm_buf_count = 0;
+    return r == ncclSuccess ? 0 : ctx_fail(ctx, std::string("ncclCommDestroy: ") + rccl()->GetErrorString(r));
+}
+
+int mz_broadcast_weights(mz_ctx* ctx, int root) {
+    if (!ctx) return -1;
+    if (!ctx->comm) return ctx_fail(ctx, "mz_comm_init has not been called");
+    if (root < 0 || root >= ctx->comm_world) return ctx_fail(ctx, "root out of range");
+    if (ctx->comm_rank == root && !ctx->weights_loaded) return ctx_fail(ctx, "the root rank has no weights loaded");
+    HIP_TRY(hipSetDevice(ctx->device));
+    // in place on the fp32 master blob, on the context's stream (ordered behind any search still queued there)
+    NCCL_TRY(rccl()->Broadcast(ctx->w_master, ctx->w_master, ctx->n_params, ncclFloat32, root, (ncclComm_t)ctx->comm,
+                               ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->comm_rank == root) return 0;   // the root's packed copies already match its blob
+    return mz_commit_weights(ctx);
+}
+
+int mz_gather_stats(mz_ctx* ctx, const double* in, int n, double* out) {
+    if (!ctx || !in || !out) return ctx_fail(ctx, "null argument");
+    if (n < 1) return ctx_fail(ctx, "n must be >= 1");
+    if (!ctx->comm) return ctx_fail(ctx, "mz_comm_init has not been called");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t need = (size_t)n * (ctx->comm_world + 1);
+    if (ctx->comm_buf_count < need) {
+        if (ctx->comm_buf) (void)hipFree(ctx->comm_buf);
+        ctx->comm_buf = nullptr;
+        ctx->comm_buf_count = 0;
+        void* p = nullptr;
+        HIP_TRY(hipMalloc(&p, need * sizeof(double)));
+        ctx->comm_buf = (double*)p;
+        ctx->comm_buf_count = need;
+    }
+    double* send = ctx->comm_buf;
+    double* recv = ctx->comm_buf + n;
+    HIP_TRY(hipMemcpyAsync(send, in, (size_t)n * sizeof(double), hipMemcpyDefault, ctx->stream));
+    NCCL_TRY(rccl()->AllGather(send, recv, (size_t)n, ncclFloat64, (ncclComm_t)ctx->comm, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(out, recv, (size_t)n * ctx->comm_world * sizeof(double), hipMemcpyDefault, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int mz_comm_barrier(mz_ctx* ctx) {
+    if (!ctx) return -1;
+    double one = 1.0;
+    std::vector<double> all((size_t)std::max(ctx->comm_world, 1));
+    return mz_gather_stats(ctx, &one, 1, all.data());
 }
 
 int mz_initial_inference(mz_ctx* ctx, int B, const float* obs, const int32_t* dst_slot, float* logits, float* policy,
@@ -828,6 +986,18 @@ int mz_recurrent_inference(mz_ctx* ctx, int B, const int32_t* src_slot, const in
         src[g] = (int)(base + src_slot[g]);
         dst[g] = (int)(base + dst_slot[g]);
         act[g] = action[g];
+    }
+    {
+        // one launch reads every parent and writes every child: a destination that is another sample's source (or
+        // destination) would race
+        std::vector<int> writer(std::max(ctx->cfg.pool_slots, 1), -1);
+        for (int g = 0; g < B; g++) {
+            if (writer[dst_slot[g]] >= 0) return ctx_fail(ctx, "dst_slot values must be distinct");
+            writer[dst_slot[g]] = g;
+        }
+        for (int g = 0; g < B; g++)
+            if (writer[src_slot[g]] >= 0 && writer[src_slot[g]] != g)
+                return ctx_fail(ctx, "dst_slot of one sample equals src_slot of another");
     }
     HIP_TRY(hipMemcpyAsync(ctx->net_src, src.data(), B * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(ctx->net_dst, dst.data(), B * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
@@ -905,9 +1075,78 @@ int mz_get_recording(mz_ctx* ctx, float* init_logits, float* init_policy, double
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     void* dst[6] = {init_logits, init_policy, init_value, sim_logits, sim_policy, sim_value};
+    // game-major buffers: the first rec_B games are a prefix
+    const size_t B = (size_t)ctx->rec_B, A = ctx->nd.A, S = ctx->cfg.max_simulations;
+    const size_t bytes[6] = {B * A * 4, B * A * 4, B * 8, B * S * A * 4, B * S * A * 4, B * S * 8};
     for (int i = 0; i < 6; i++)
-        if (dst[i]) HIP_TRY(hipMemcpy(dst[i], ctx->rec_buf[i].p, ctx->rec_buf[i].bytes, hipMemcpyDefault));
+        if (dst[i] && bytes[i]) HIP_TRY(hipMemcpy(dst[i], ctx->rec_buf[i].p, bytes[i], hipMemcpyDefault));
     return 0;
+}
+
+int mz_get_recording_games(mz_ctx* ctx) { return (ctx && ctx->recording) ? ctx->rec_B : 0; }
+
+int mz_get_gumbel(mz_ctx* ctx, double* gumbel) {
+    if (!ctx || !gumbel) return ctx_fail(ctx, "null argument");
+    const size_t B = (size_t)ctx->last_B, A = ctx->nd.A;
+    if (!B) return ctx_fail(ctx, "no search has run");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    std::vector<double> rg(B * A), out(B * A, 0.0);
+    std::vector<int> ra(B * A);
+    std::vector<GameState> gs(B);
+    HIP_TRY(hipMemcpy(rg.data(), ctx->ts.root_gumbel, B * A * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(ra.data(), ctx->ts.root_action, B * A * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(gs.data(), ctx->ts.gs, B * sizeof(GameState), hipMemcpyDeviceToHost));
+    for (size_t g = 0; g < B; g++) {
+        if (gs[g].L < 2 || gs[g].L > (int)A) continue;   // shortcut / failed games drew nothing
+        for (int j = 0; j < gs[g].L; j++) out[g * A + ra[g * A + j]] = rg[g * A + j];
+    }
+    HIP_TRY(hipMemcpy(gumbel, out.data(), B * A * 8, hipMemcpyDefault));
+    return 0;
+}
+
+int mz_seed_gumbel(mz_ctx* ctx, uint64_t seed, uint64_t move_counter) {
+    if (!ctx) return -1;
+    ctx->gumbel_seed = seed;
+    ctx->gumbel_move = move_counter;
+    return 0;
+}
+
+int mz_child_order(const uint8_t* legal, int A, int32_t* order) {
+    if (!legal || !order || A < 1) return -1;
+    // java.util.HashMap<Action, Node> filled in ascending action order (Node.java:295-304): bucket
+    // (59 + index) & (T - 1), T doubling from 16 when size > 0.75 T or when a bin of a table < 64 reaches 9 entries
+    // (treeifyBin resizes instead); iteration = buckets ascending, insertion order inside a bucket.
+    int T = 16, thr = 12, size = 0;
+    std::vector<int> cnt(64, 0);
+    for (int a = 0; a < A && T < 64; a++) {
+        if (!legal[a]) continue;
+        const int c = ++cnt[(59 + a) & (T - 1)];
+        size++;
+        for (int pass = 0; pass < 2; pass++) {
+            const bool grow = pass == 0 ? (c >= 9) : (size > thr);
+            if (!grow) continue;
+            T *= 2;
+            thr *= 2;
+            if (T < 64) {
+                std::fill(cnt.begin(), cnt.end(), 0);
+                for (int a2 = 0; a2 <= a; a2++)
+                    if (legal[a2]) cnt[(59 + a2) & (T - 1)]++;
+            }
+        }
+    }
+    int L = 0;
+    for (int a = 0; a < A; a++) L += legal[a] ? 1 : 0;
+    while (L > thr) {
+        T *= 2;
+        thr *= 2;
+    }
+    std::vector<std::pair<int, int>> k;
+    for (int a = 0; a < A; a++)
+        if (legal[a]) k.push_back({(59 + a) & (T - 1), a});
+    std::stable_sort(k.begin(), k.end());
+    for (int j = 0; j < L; j++) order[j] = k[j].second;
+    return L;
 }
 
 int mz_tree_num_nodes(mz_ctx* ctx, int game) {

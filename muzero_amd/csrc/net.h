@@ -50,8 +50,14 @@ struct NetIO {
     int B;
 };
 
+// Opt a kernel in to > 64 KiB of dynamic LDS.  hipFuncSetAttribute applies to the function on the CURRENT device, so
+// the "already done" state is kept per (function, device) - one process may hold contexts on several GPUs - and under a
+// lock.  A failure is remembered for take_optin_error(), which the forward entry points report.
+void lds_optin(const void* fn);
+hipError_t take_optin_error();
+
 size_t fp32_lds_bytes(const NetDims& d);
-void launch_net_fp32(hipStream_t st, bool initial, const NetDims& d, const NetProgramF32* prog_dev,
-                     const float* wbuf, const NetIO& io);
+hipError_t launch_net_fp32(hipStream_t st, bool initial, const NetDims& d, const NetProgramF32* prog_dev,
+                           const float* wbuf, const NetIO& io);
 
 }  // namespace mz

@@ -11,6 +11,10 @@
 // b_inference/InitialInferenceListTranslator.java:44-112 (softmax, value = valueSpan/2 * v).
 #include "net.h"
 
+#include <mutex>
+#include <set>
+#include <utility>
+
 #include <math.h>
 
 namespace mz {
@@ -278,27 +282,41 @@ size_t fp32_lds_bytes(const NetDims& d) {
     return (3 * fp32_buf_floats(d) + 8) * sizeof(float) + (size_t)9 * d.HW * sizeof(short) + 16;
 }
 
-void launch_net_fp32(hipStream_t st, bool initial, const NetDims& d, const NetProgramF32* prog_dev, const float* wbuf,
-                     const NetIO& io) {
+namespace {
+std::mutex g_optin_mu;
+std::set<std::pair<const void*, int>> g_optin_done;
+thread_local hipError_t g_optin_err = hipSuccess;
+}  // namespace
+
+void lds_optin(const void* fn) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess) {
+        std::lock_guard<std::mutex> lk(g_optin_mu);
+        if (g_optin_done.count({fn, dev})) return;
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) g_optin_done.insert({fn, dev});
+    }
+    if (e != hipSuccess) g_optin_err = e;
+}
+hipError_t take_optin_error() {
+    const hipError_t e = g_optin_err;
+    g_optin_err = hipSuccess;
+    return e;
+}
+
+hipError_t launch_net_fp32(hipStream_t st, bool initial, const NetDims& d, const NetProgramF32* prog_dev, const float* wbuf,
+                           const NetIO& io) {
     const size_t lds = fp32_lds_bytes(d);
     const int bf = (int)fp32_buf_floats(d);
     if (initial) {
-        static bool set = false;
-        if (!set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_net_fp32<true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            set = true;
-        }
+        lds_optin(reinterpret_cast<const void*>(&k_net_fp32<true>));
         hipLaunchKernelGGL(k_net_fp32<true>, dim3(io.B), dim3(NT), lds, st, d, prog_dev, wbuf, io, bf);
     } else {
-        static bool set = false;
-        if (!set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_net_fp32<false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            set = true;
-        }
+        lds_optin(reinterpret_cast<const void*>(&k_net_fp32<false>));
         hipLaunchKernelGGL(k_net_fp32<false>, dim3(io.B), dim3(NT), lds, st, d, prog_dev, wbuf, io, bf);
     }
+    return take_optin_error();
 }
 
 }  // namespace mz

@@ -1715,47 +1715,27 @@ namespace {
 template <class G, int IN, int OUT>
 void launch_seg(MfmaNet* n, hipStream_t st, int grid, const NetDims& d, const TowerDev& tw, const NetIO& io, int b0,
                 int b1) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_seg<G, IN, OUT>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    lds_optin(reinterpret_cast<const void*>(&k_seg<G, IN, OUT>));
     hipLaunchKernelGGL((k_seg<G, IN, OUT>), dim3(grid), dim3(G::NT), n->Lseg.total, st, d, tw, n->hd, io, n->Lseg, n->NB,
                        b0, b1);
 }
 
 template <class G, int KSB>
 void launch_bcast(MfmaNet* n, hipStream_t st, int grid, const NetDims& d, const TowerDev& tw, const NetIO& io, int blk) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bcast<G, KSB>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    lds_optin(reinterpret_cast<const void*>(&k_bcast<G, KSB>));
     hipLaunchKernelGGL((k_bcast<G, KSB>), dim3(grid), dim3(G::NT), n->Lbc.total, st, d, tw, io, n->Lbc, n->NB, blk);
 }
 
 template <class G, int KSB, int OUT>
 void launch_bseg(MfmaNet* n, hipStream_t st, int grid, const NetDims& d, const TowerDev& tw, const NetIO& io, int blk, int b0,
                  int b1) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bseg<G, KSB, OUT>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    lds_optin(reinterpret_cast<const void*>(&k_bseg<G, KSB, OUT>));
     hipLaunchKernelGGL((k_bseg<G, KSB, OUT>), dim3(grid), dim3(G::NT), n->Lbc.total, st, d, tw, n->hd, io, n->Lbc, n->NB,
                        blk, b0, b1);
 }
 template <class G, int IN, int KSB>
 void launch_tower(MfmaNet* n, hipStream_t st, int grid, const NetDims& d, const TowerDev& tw, const NetIO& io, int blk) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tower<G, IN, KSB, OUT_FINAL>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    lds_optin(reinterpret_cast<const void*>(&k_tower<G, IN, KSB, OUT_FINAL>));
     hipLaunchKernelGGL((k_tower<G, IN, KSB, OUT_FINAL>), dim3(grid), dim3(G::NT), n->Ltw.total, st, d, tw, n->hd, io, n->Ltw,
                        n->NB, blk, d.R);
 }
@@ -1880,11 +1860,17 @@ int mfma_forward(MfmaNet* n, hipStream_t st, bool initial, const NetDims& d, con
         if (err) *err = "batch exceeds the context's inference capacity";
         return -1;
     }
+    int rc;
     switch (n->geom) {
-        case 0: return forward_t<Geo<128, 64, 1, 8, 24, 2>>(n, st, initial, d, io);
-        case 1: return forward_t<Geo<256, 128, 2, 8, 24, 2>>(n, st, initial, d, io);
-        default: return forward_t<Geo<128, 64, 1, 4, 24, 1, 2>>(n, st, initial, d, io);
+        case 0: rc = forward_t<Geo<128, 64, 1, 8, 24, 2>>(n, st, initial, d, io); break;
+        case 1: rc = forward_t<Geo<256, 128, 2, 8, 24, 2>>(n, st, initial, d, io); break;
+        default: rc = forward_t<Geo<128, 64, 1, 4, 24, 1, 2>>(n, st, initial, d, io); break;
     }
+    if (hipError_t e = take_optin_error()) {
+        if (err) *err = std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(e);
+        return -1;
+    }
+    return rc;
 }
 
 }  // namespace mz

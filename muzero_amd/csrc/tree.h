@@ -14,6 +14,10 @@ struct TreeParams {
     int B, A, N;  // games, action space, node slots per game (= max_simulations + 1)
     int m0, c_visit, two_players, known_bounds, hybrid, gumbel_sel;
     double c_scale, discount, bmin, bmax, frac, temp_root;
+    // device-drawn Gumbel noise (used when the caller passes no noise array): Philox4x32-10 keyed by gumbel_seed,
+    // counter = (action, game, move counter)
+    int device_gumbel;
+    unsigned long long gumbel_seed, gumbel_move;
 };
 
 // Per-game scalars (array of structs; one wave touches one entry).
@@ -101,7 +105,7 @@ void launch_root(hipStream_t st, const TreeParams& P, const TreeStore& T, const 
                  const int* nsims, int n_default, NetOut init, const double* gumbel, const double* dirichlet,
                  Recording rec);
 void launch_select(hipStream_t st, const TreeParams& P, const TreeStore& T, int* net_src, int* net_dst, int* net_action,
-                   int* net_active, int* any_active);
+                   int* net_active);
 void launch_backup(hipStream_t st, const TreeParams& P, const TreeStore& T, NetOut out, Recording rec);
 void launch_finish(hipStream_t st, const TreeParams& P, const TreeStore& T, const uint8_t* exploration_time,
                    const double* u, DeviceMoveOutputs o, unsigned long long* stats);

@@ -220,6 +220,29 @@ __device__ __forceinline__ unsigned top_m_select(const double* score, int n, int
     return selected;
 }
 
+// Philox4x32-10 (Salmon et al., SC'11): counter (c0..c3), key (k0, k1) -> 4 x 32 random bits.
+__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const unsigned long long p0 = 0xD2511F53ull * c[0], p1 = 0xCD9E8D57ull * c[2];
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1;
+        c[1] = (unsigned)p1;
+        c[3] = (unsigned)p0;
+        c[0] = n0;
+        c[2] = n2;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+// GumbelFunctions.drawGumble (:48-54): -log(-log(u)), u uniform; here u = (53 random bits + 0.5) / 2^53 in (0, 1)
+__device__ __forceinline__ double device_gumbel(const TreeParams& P, int g, int a) {
+    unsigned c[4] = {(unsigned)a, (unsigned)g, (unsigned)P.gumbel_move, (unsigned)(P.gumbel_move >> 32)};
+    philox4x32_10(c, (unsigned)P.gumbel_seed, (unsigned)(P.gumbel_seed >> 32));
+    const unsigned long long bits = (((unsigned long long)c[0] << 32) | c[1]) >> 11;
+    const double u = ((double)bits + 0.5) * (1.0 / 9007199254740992.0);
+    return -log(-log(u));
+}
+
 // ---------------------------------------------------------------------------------------------
 // Root: storeEntropyInfo, one-legal-action shortcut, GumbelSearch.<init>, expandRootNode,
 // addExplorationNoise, gumbelActionsStart.
@@ -357,7 +380,7 @@ __global__ __launch_bounds__(W) void k_root(TreeParams P, TreeStore T, const uin
                 prior = prior * (1.0 - P.frac) + dirichlet[(long long)g * A + a] * P.frac;
                 logit = log(prior);
             }
-            double gv = gumbel ? gumbel[(long long)g * A + a] : 0.0;
+            double gv = gumbel ? gumbel[(long long)g * A + a] : (P.device_gumbel ? device_gumbel(P, g, a) : 0.0);
             T.root_action[(long long)g * A + j] = a;
             T.root_ipv[(long long)g * A + j] = ipv;
             T.root_logit[(long long)g * A + j] = logit;
@@ -430,7 +453,7 @@ __global__ __launch_bounds__(W) void k_root(TreeParams P, TreeStore T, const uin
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(W) void k_select(TreeParams P, TreeStore T, int* __restrict__ net_src,
                                               int* __restrict__ net_dst, int* __restrict__ net_action,
-                                              int* __restrict__ net_active, int* __restrict__ any_active) {
+                                              int* __restrict__ net_active) {
     const int g = blockIdx.x, lane = threadIdx.x, A = P.A;
     const long long gn = (long long)g * P.N;
     GameState* S = &T.gs[g];
@@ -495,7 +518,6 @@ __global__ __launch_bounds__(W) void k_select(TreeParams P, TreeStore T, int* __
         net_dst[g] = (int)(gn + S->num_nodes);
         net_action[g] = action;
         net_active[g] = 1;
-        *any_active = 1;
     }
 }
 
@@ -888,9 +910,8 @@ void launch_root(hipStream_t st, const TreeParams& P, const TreeStore& T, const 
                        dirichlet, rec);
 }
 void launch_select(hipStream_t st, const TreeParams& P, const TreeStore& T, int* net_src, int* net_dst, int* net_action,
-                   int* net_active, int* any_active) {
-    hipLaunchKernelGGL(k_select, dim3(P.B), dim3(W), 0, st, P, T, net_src, net_dst, net_action, net_active,
-                       any_active);
+                   int* net_active) {
+    hipLaunchKernelGGL(k_select, dim3(P.B), dim3(W), 0, st, P, T, net_src, net_dst, net_action, net_active);
 }
 void launch_backup(hipStream_t st, const TreeParams& P, const TreeStore& T, NetOut out, Recording rec) {
     hipLaunchKernelGGL(k_backup, dim3(P.B), dim3(W), 0, st, P, T, out, rec);

@@ -163,7 +163,7 @@ std::vector<int32_t> MuZeroConfig::actionCells() const {
 }
 
 mz_config MuZeroConfig::toNative(int maxGames, int precision) const {
-    mz_config c;
+    mz_config c{};
     std::memset(&c, 0, sizeof(c));
     c.net.height = boardHeight;
     c.net.width = boardWidth;

@@ -29,8 +29,8 @@ def test_header_symbols_are_exported():
 def test_struct_layouts_match_header():
     # sizes the C compiler gives the same structs (LP64, natural alignment)
     assert C.sizeof(capi.NetConfig) == 48
-    assert C.sizeof(capi.SearchConfig) == 72
-    assert C.sizeof(capi.Config) == 48 + 72 + 16
+    assert C.sizeof(capi.SearchConfig) == 88
+    assert C.sizeof(capi.Config) == 48 + 88 + 16
     assert C.sizeof(capi.MoveOutputs) == 14 * 8
 
 
@@ -52,3 +52,23 @@ def test_param_count_formula_matches_tensor_list():
     assert abs(fl["recurrent"] / 1e6 - 191.8) < 0.2 and abs(fl["initial"] / 1e6 - 170.8) < 0.2
     fl = netspec.flops_per_sample(netspec.spec_tictactoe())
     assert abs(fl["recurrent"] / 1e6 - 49.6) < 0.2
+
+
+def test_child_order_helper_matches_the_oracle_hashmap():
+    """mz_child_order (host-side helper for replaying a reference Dirichlet vector, which the reference applies
+    by child index, Node.java:353-358) against the oracle's java.util.HashMap emulation."""
+    import numpy as np
+    from oracle import search as osr
+    rng = np.random.default_rng(0)
+    for A in (9, 26, 82, 196):
+        masks = [np.ones(A, np.uint8)]
+        for _ in range(40):
+            masks.append((rng.uniform(size=A) < rng.uniform(0.05, 0.95)).astype(np.uint8))
+        m = np.zeros(A, np.uint8)
+        m[[i for i in range(A) if i % 16 == 5][:12]] = 1   # one bucket at T = 16: the ninth entry forces a resize
+        masks.append(m)
+        for legal in masks:
+            keys = np.nonzero(legal)[0]
+            if len(keys) == 0:
+                continue
+            assert capi.child_order(legal).tolist() == osr.hashmap_order(keys)

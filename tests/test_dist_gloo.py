@@ -1,5 +1,7 @@
-"""world_size-2 gloo test of the N>1 host path (runs on CPU): contiguous game sharding, weight-blob
-broadcast from rank 0, gather of per-rank episode statistics, max-over-ranks timing."""
+"""world_size-2 tests of the N>1 host path (run on CPU): contiguous game sharding, weight-blob broadcast from
+rank 0, gather of per-rank episode statistics, max-over-ranks timing over gloo (HostComm: the same four
+operations NativeComm runs over RCCL through the C ABI on a GPU box), and the rendezvous that hands rank 0's
+RCCL id to the other ranks."""
 import os
 import socket
 
@@ -22,20 +24,21 @@ def _free_port():
 def _worker(rank, world, port, total_games, q):
     os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
-    assert mzd.init("gloo")
+    comm = mzd.HostComm("gloo", torch.device("cpu"))
+    assert comm.active and comm.rank == rank and comm.world == world
     spec = netspec.spec_tiny()
     weights = netspec.random_weights(spec, seed=7) if rank == 0 else None
-    blob = mzd.blob_tensor(spec, weights, torch.device("cpu"))
+    blob = comm.blob_tensor(spec, weights)
     if rank != 0:
         blob.fill_(-1.0)
-    mzd.broadcast_weights(blob, src=0)
+    comm.broadcast_weights(blob, root=0)
     lo, hi = mzd.shard_range(total_games, rank, world)
     sims = (hi - lo) * 20                                 # every game of the shard runs n = 20 simulations
-    stats = mzd.gather_stats([hi - lo, sims, float(blob.double().sum())])
-    tmax = mzd.max_over_ranks(1.0 + rank)
-    mzd.barrier()
+    stats = comm.gather_stats([hi - lo, sims, float(blob.double().sum())])
+    tmax = comm.max_over_ranks(1.0 + rank)
+    comm.barrier()
     q.put((rank, lo, hi, stats.tolist(), tmax, float(blob[:5].sum())))
-    torch.distributed.destroy_process_group()
+    comm.close()
 
 
 def test_two_rank_sharding_broadcast_and_gather():
@@ -69,3 +72,26 @@ def test_shard_range_partitions_exactly():
             assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
             sizes = [b - a for a, b in parts]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _id_worker(rank, world, port, q):
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    store = mzd.rendezvous_store(rank, world)
+    uid = mzd.exchange_unique_id(store, rank, lambda: bytes(range(128)))   # stand-in for mz_comm_unique_id
+    q.put((rank, uid))
+
+
+def test_unique_id_rendezvous_without_a_process_group():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_id_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1] == bytes(range(128))

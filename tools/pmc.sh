@@ -1,9 +1,11 @@
 #!/bin/bash
 # PMC passes for the inference kernels (each pass its own run, within the per-block counter limits).
-# Usage (on the GPU box): bash tools/pmc.sh <tag> [games]   -> gpurun_out/pmc_<tag>/summary.txt
+# Usage (on the GPU box): bash tools/pmc.sh <tag> [games] [workload]
+#   -> gpurun_out/pmc_<tag>/summary.txt and traffic_<workload>_<games>.json (copy both into profiles/)
 set -e
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$1
 GAMES=${2:-4096}
+WL=${3:-go9}
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS"
@@ -14,11 +16,12 @@ P5="GRBM_GUI_ACTIVE"
 i=0
 for P in "$P1" "$P2" "$P3" "$P4" "$P5"; do
   i=$((i+1))
-  timeout -s KILL 120 rocprofv3 --pmc $P --output-format csv -d $OUT/p$i -- python3 $GRAFT_REPO_ROOT/tools/bench_net.py --games $GAMES --iters 3 > $OUT/p$i.log 2>&1
+  timeout -s KILL 120 rocprofv3 --pmc $P --output-format csv -d $OUT/p$i -- python3 $GRAFT_REPO_ROOT/tools/bench_net.py --workload $WL --games $GAMES --iters 3 > $OUT/p$i.log 2>&1
 done
 python3 - <<PY > $OUT/summary.txt
-import csv, glob, collections
-print("# per-dispatch averages over the recurrentInference launches of tools/bench_net.py --games $GAMES (rocprofv3 --pmc, one pass per counter group)")
+import csv, glob, collections, json, re
+print("# per-dispatch averages over the recurrentInference launches of tools/bench_net.py --workload $WL --games $GAMES (rocprofv3 --pmc, one pass per counter group)")
+traffic = {"fetch": {}, "write": {}}
 for i in (1, 2, 3, 4, 5):
     fs = glob.glob("$OUT/p%d/**/*counter_collection.csv" % i, recursive=True)
     agg = collections.defaultdict(lambda: collections.defaultdict(float)); disp = collections.defaultdict(set)
@@ -31,5 +34,20 @@ for i in (1, 2, 3, 4, 5):
         if any(t in k for t in ("k_seg", "k_bcast", "k_bseg", "k_tower", "k_heads")):
             n = len(disp[k])
             print(f"{k:46s} dispatches {n:3d}  " + "  ".join(f"{a}={b / n:.4g}" for a, b in sorted(v.items())))
+            # the recurrent chain only (IN_OBS kernels belong to the one initialInference that sets the states up)
+            # (the kernels whose 2nd template argument IN is 0 = IN_OBS belong to the one initialInference that sets the states up)
+            rec = not re.search(r"Geo<[^>]*>, 0,", k)
+            if "FETCH_SIZE" in v and rec: traffic["fetch"][k] = v["FETCH_SIZE"] / n
+            if "WRITE_SIZE" in v and rec: traffic["write"][k] = v["WRITE_SIZE"] / n
+# HBM bytes per recurrentInference launch chain.  gfx950: FETCH_SIZE (KB) tallies 128-B requests at 64 B for wide
+# coalesced reads -> doubled; WRITE_SIZE (KB) is exact (MI355X_MICROARCH.md, HBM).
+fetch_kb = sum(traffic["fetch"].values()); write_kb = sum(traffic["write"].values())
+json.dump({"source": "tools/pmc.sh $1 $GAMES $WL: tools/bench_net.py, FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc passes",
+           "workload": "$WL", "precision": "bf16", "games": $GAMES,
+           "fetch_size_kb_per_launch": traffic["fetch"], "write_size_kb_per_launch": traffic["write"],
+           "note": "gfx950: FETCH_SIZE tallies 128-B requests at 64 B -> doubled; WRITE_SIZE exact",
+           "bytes_per_sample": (2 * fetch_kb + write_kb) * 1024.0 / $GAMES},
+          open("$OUT/traffic_${WL}_$GAMES.json", "w"), indent=1)
 PY
+cat $OUT/traffic_${WL}_$GAMES.json
 cat $OUT/summary.txt
