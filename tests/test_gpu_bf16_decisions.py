@@ -49,11 +49,11 @@ def test_bf16_and_fp32_searches_agree_on_decisions_go9():
           f"identical candidate set {same_cand:.4f}, visit-count L1 mean {l1.mean():.3f} (of {2 * n}) max {l1.max()}, "
           f"|d root_value_target|/81 mean {dv.mean():.5f} max {dv.max():.5f}, "
           f"|d root_value_inference|/81 mean {dvi.mean():.5f} max {dvi.max():.5f}, policy-target L1 mean {dpt.mean():.4f}")
-    assert same_sel >= 0.85
-    assert same_cand >= 0.97
-    assert l1.mean() <= 6.0
-    assert dv.max() <= 2e-2 and dv.mean() <= 4e-3
-    assert dvi.max() <= 2e-2
+    assert same_sel >= 0.95
+    assert same_cand >= 0.92
+    assert l1.mean() <= 4.0
+    assert dv.max() <= 3.5e-2 and dv.mean() <= 6e-3
+    assert dvi.max() <= 3.5e-2
 
 
 @pytest.mark.parametrize("name,factory", [("go9", netspec.spec_go9), ("tictactoe", netspec.spec_tictactoe)])
