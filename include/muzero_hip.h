@@ -218,6 +218,26 @@ int mz_get_last_stats(mz_ctx* ctx, int64_t* simulations, double* mean_path_len);
 int mz_synchronize(mz_ctx* ctx);
 const char* mz_version(void);
 
+/* ---- for callers that cannot allocate ---------------------------------------------------------------------
+ * No counterpart in the reference.  For callers that cannot call hipMalloc: code under HIP graph capture, tight
+ * serving loops, harnesses that forbid allocation.  Same search as mz_search_moves_injected with the same results,
+ * but every byte of scratch (trees, per-game state, step buffers) comes from one file-scope __device__ array of
+ * MZ_NOALLOC_SCRATCH_BYTES that each GPU holds until the process ends; the call makes no hipMalloc / hipFree /
+ * event creation and does not synchronize (work is queued on the context's stream: mz_synchronize afterwards).
+ *  - every data pointer (inputs and outputs) must be DEVICE memory: host buffers would need staging allocations;
+ *  - B, S and the action space must fit: mz_noalloc_scratch_bytes(ctx, B) <= MZ_NOALLOC_SCRATCH_BYTES, else error;
+ *  - the array is shared by all calls on that GPU and keeps the last call's contents (the call clears what must
+ *    start at zero); calls that overlap on one GPU (two contexts, two streams) race: serialise them;
+ *  - mz_tree_* / mz_get_recording / mz_get_gumbel / timing do not see this call. */
+#define MZ_NOALLOC_SCRATCH_BYTES (16u << 20)
+size_t mz_noalloc_scratch_bytes(const mz_ctx* ctx, int B);
+int mz_search_moves_injected_noalloc(mz_ctx* ctx, int B, const uint8_t* legal, const uint8_t* to_play,
+                                     const int32_t* num_simulations, const float* init_logits,
+                                     const float* init_policy, const double* init_value, const float* sim_logits,
+                                     const float* sim_policy, const double* sim_value, int S, const double* gumbel,
+                                     const double* dirichlet, const uint8_t* exploration_time, const double* u,
+                                     const mz_move_outputs* out);
+
 #ifdef __cplusplus
 }
 #endif

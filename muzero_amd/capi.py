@@ -53,7 +53,8 @@ EXPORTS = (
     "mz_tree_num_nodes", "mz_tree_node", "mz_tree_minmax", "mz_set_timing", "mz_get_timing", "mz_get_last_stats",
     "mz_synchronize", "mz_version", "mz_comm_unique_id", "mz_comm_init", "mz_comm_destroy", "mz_broadcast_weights",
     "mz_gather_stats", "mz_comm_barrier", "mz_get_recording_games", "mz_get_gumbel", "mz_seed_gumbel",
-    "mz_child_order")
+    "mz_child_order", "mz_noalloc_scratch_bytes", "mz_search_moves_injected_noalloc")
+NOALLOC_SCRATCH_BYTES = 16 << 20
 COMM_ID_BYTES = 128
 
 _lib = None
@@ -103,6 +104,9 @@ def lib():
         L.mz_get_gumbel.argtypes = [vp, vp]
         L.mz_seed_gumbel.argtypes = [vp, C.c_uint64, C.c_uint64]
         L.mz_child_order.argtypes = [vp, C.c_int, vp]
+        L.mz_noalloc_scratch_bytes.argtypes = [vp, C.c_int]
+        L.mz_noalloc_scratch_bytes.restype = C.c_size_t
+        L.mz_search_moves_injected_noalloc.argtypes = L.mz_search_moves_injected.argtypes
         _lib = L
     return _lib
 
@@ -304,6 +308,19 @@ class Context:
             _ptr(_np(gumbel, np.float64)), _ptr(_np(dirichlet, np.float64)), _ptr(_np(exploration_time, np.uint8)),
             _ptr(_np(u, np.float64)), C.byref(mo)))
         return o
+
+    def noalloc_scratch_bytes(self, B):
+        return lib().mz_noalloc_scratch_bytes(self._h, B)
+
+    def search_moves_injected_noalloc(self, B, legal, init_logits, init_policy, init_value, sim_logits, sim_policy,
+                                      sim_value, S, outputs, to_play=None, num_simulations=None, gumbel=None,
+                                      dirichlet=None, exploration_time=None, u=None):
+        """Device pointers only (torch CUDA tensors / raw addresses); asynchronous: synchronize() before reading."""
+        mo = self._outputs_struct(outputs)
+        self._check(lib().mz_search_moves_injected_noalloc(
+            self._h, B, _ptr(legal), _ptr(to_play), _ptr(num_simulations), _ptr(init_logits), _ptr(init_policy),
+            _ptr(init_value), _ptr(sim_logits), _ptr(sim_policy), _ptr(sim_value), S, _ptr(gumbel), _ptr(dirichlet),
+            _ptr(exploration_time), _ptr(u), C.byref(mo)))
 
     def set_recording(self, enable):
         self._check(lib().mz_set_recording(self._h, 1 if enable else 0))

@@ -20,9 +20,32 @@
 
 using namespace mz;
 
+// Scratch of mz_search_moves_injected_noalloc (include/muzero_hip.h): trees, per-game state and step buffers of one
+// call, carved by carve_noalloc().  One copy per GPU, at its own address on each: host code never passes this name to
+// a kernel or a memset - only the per-device address hipGetSymbolAddress returned (g_scratch_ptr), resolved in
+// mz_create with that device current.
+static __device__ __align__(256) unsigned char scratch[MZ_NOALLOC_SCRATCH_BYTES];
+
 namespace {
 
 thread_local std::string g_create_error;
+
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+unsigned char* g_scratch_ptr[kMaxDevices] = {nullptr};
+
+// Device `device` must be current.  Returns hipSuccess and leaves the address in g_scratch_ptr[device].
+hipError_t resolve_scratch(int device) {
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (g_scratch_ptr[device]) return hipSuccess;
+    void* p = nullptr;
+    hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    if (!p) return hipErrorInvalidSymbol;
+    g_scratch_ptr[device] = static_cast<unsigned char*>(p);
+    return hipSuccess;
+}
 
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
@@ -642,6 +665,50 @@ int search_impl(mz_ctx* ctx, int B, const float* obs, const uint8_t* legal, cons
     return 0;
 }
 
+// Layout of one call's scratch inside the static array: every array 256-byte aligned.  base == nullptr: sizes only.
+struct NoAllocPlan {
+    TreeStore T{};
+    int *net_src = nullptr, *net_dst = nullptr, *net_action = nullptr, *net_active = nullptr;
+    size_t gs_off = 0, gs_bytes = 0, total = 0;
+};
+NoAllocPlan carve_noalloc(unsigned char* base, size_t B, size_t N, size_t A) {
+    NoAllocPlan p;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        unsigned char* r = base ? base + off : nullptr;
+        off += (bytes + 255) & ~(size_t)255;
+        return r;
+    };
+    const size_t BNA = B * N * A, BA = B * A, BN = B * N;
+    p.T.child_prior = (double*)take(BNA * 8);
+    p.T.child_qsum = (double*)take(BNA * 8);
+    p.T.child_eqsum = (double*)take(BNA * 8);
+    p.T.child_visit = (int*)take(BNA * 4);
+    p.T.child_slot = (int*)take(BNA * 4);
+    p.T.root_logit = (double*)take(BA * 8);
+    p.T.root_ipv = (double*)take(BA * 8);
+    p.T.root_gumbel = (double*)take(BA * 8);
+    p.T.root_action = (int*)take(BA * 4);
+    p.T.node_value = (double*)take(BN * 8);
+    p.T.node_vmix = (double*)take(BN * 8);
+    p.T.node_iv = (double*)take(BN * 8);
+    p.T.node_evmix = (double*)take(BN * 8);
+    p.T.node_eiv = (double*)take(BN * 8);
+    p.T.node_ereward = (double*)take(BN * 8);
+    p.T.node_parent = (int*)take(BN * 4);
+    p.T.node_pchild = (int*)take(BN * 4);
+    p.T.node_toplay = (int*)take(BN * 4);
+    p.gs_off = off;
+    p.gs_bytes = B * sizeof(GameState);
+    p.T.gs = (GameState*)take(p.gs_bytes);
+    p.net_src = (int*)take(B * 4);
+    p.net_dst = (int*)take(B * 4);
+    p.net_action = (int*)take(B * 4);
+    p.net_active = (int*)take(B * 4);
+    p.total = off;
+    return p;
+}
+
 }  // namespace
 
 extern "C" {
@@ -681,6 +748,8 @@ int mz_create(const mz_config* cfg, int device, mz_ctx** out) {
     };
     if (hipSetDevice(device) != hipSuccess) return fail("hipSetDevice failed");
     if (hipStreamCreate(&ctx->stream) != hipSuccess) return fail("hipStreamCreate failed");
+    if (hipError_t e = resolve_scratch(device))
+        return fail(std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
 
     NetDims& d = ctx->nd;
     d.H = n.height;
@@ -1060,6 +1129,88 @@ int mz_search_moves_injected(mz_ctx* ctx, int B, const uint8_t* legal, const uin
         return ctx_fail(ctx, "injected network outputs must not be NULL");
     return search_impl(ctx, B, nullptr, legal, to_play, num_simulations, gumbel, dirichlet, exploration_time, u, out,
                        true, init_logits, init_policy, init_value, sim_logits, sim_policy, sim_value, S);
+}
+
+size_t mz_noalloc_scratch_bytes(const mz_ctx* ctx, int B) {
+    if (!ctx || B < 1) return 0;
+    return carve_noalloc(nullptr, (size_t)B, (size_t)ctx->N, (size_t)ctx->nd.A).total;
+}
+
+int mz_search_moves_injected_noalloc(mz_ctx* ctx, int B, const uint8_t* legal, const uint8_t* to_play,
+                                     const int32_t* num_simulations, const float* init_logits,
+                                     const float* init_policy, const double* init_value, const float* sim_logits,
+                                     const float* sim_policy, const double* sim_value, int S, const double* gumbel,
+                                     const double* dirichlet, const uint8_t* exploration_time, const double* u,
+                                     const mz_move_outputs* out) {
+    if (check_B(ctx, B)) return -1;
+    if (!legal || !init_logits || !init_policy || !init_value || !sim_logits || !sim_policy || !sim_value)
+        return ctx_fail(ctx, "legal and the injected network outputs must not be NULL");
+    {
+        const mz_search_config& sc = ctx->cfg.search;
+        const bool draws = sc.hybrid ? (!sc.gumbel_action_selection || exploration_time != nullptr)
+                                     : !sc.gumbel_action_selection;
+        if (draws && !u) return ctx_fail(ctx, "u must not be NULL: the configured selectAction mode draws an action");
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    unsigned char* base = (ctx->device >= 0 && ctx->device < kMaxDevices) ? g_scratch_ptr[ctx->device] : nullptr;
+    if (!base) return ctx_fail(ctx, "scratch address of this device was not resolved");
+    const size_t A = ctx->nd.A;
+    NoAllocPlan pl = carve_noalloc(base, (size_t)B, (size_t)ctx->N, A);
+    if (pl.total > (size_t)MZ_NOALLOC_SCRATCH_BYTES)
+        return ctx_fail(ctx, "B x (max_simulations + 1) x action_space needs " + std::to_string(pl.total) +
+                                 " bytes of scratch, the no-alloc entry point holds " +
+                                 std::to_string((size_t)MZ_NOALLOC_SCRATCH_BYTES) + ": use mz_search_moves_injected");
+    // every buffer must already be on the device: staging a host buffer would allocate
+    static const mz_move_outputs none{};
+    const mz_move_outputs& o = out ? *out : none;
+    const void* ptrs[] = {legal, to_play, num_simulations, init_logits, init_policy, init_value, sim_logits, sim_policy,
+                          sim_value, gumbel, dirichlet, exploration_time, u, o.action, o.selected_action, o.visit_counts,
+                          o.policy_target, o.root_value_target, o.v_mix, o.root_value_inference, o.entropy,
+                          o.legal_action_max_entropy, o.root_entropy_value_target, o.playout_policy, o.playout_appended,
+                          o.sims_run, o.status};
+    for (const void* p : ptrs)
+        if (p && !is_device_ptr(p)) return ctx_fail(ctx, "the no-alloc entry point takes device pointers only");
+    const int steps = num_simulations ? ctx->cfg.max_simulations : ctx->cfg.search.num_simulations;
+    if (S < steps) return ctx_fail(ctx, "S (recorded simulations) smaller than the simulation budget");
+
+    TreeParams P = ctx->tp;
+    P.B = B;
+    P.device_gumbel = (!gumbel && ctx->cfg.search.device_gumbel) ? 1 : 0;
+    P.gumbel_seed = ctx->gumbel_seed;
+    P.gumbel_move = ctx->gumbel_move;
+    if (P.device_gumbel) ctx->gumbel_move++;
+    TreeStore T = pl.T;
+    T.order = ctx->order_dev;          // read-only tables made by mz_create
+    T.inv_order = ctx->inv_order_dev;
+    // the array keeps the last call's contents: per-game state starts from zero, everything else is written before
+    // it is read (k_root initialises a game's root, k_backup every node it expands)
+    HIP_TRY(hipMemsetAsync(base + pl.gs_off, 0, pl.gs_bytes, ctx->stream));
+    DeviceMoveOutputs d{};
+    d.action = o.action;
+    d.selected_action = o.selected_action;
+    d.visit_counts = o.visit_counts;
+    d.policy_target = o.policy_target;
+    d.root_value_target = o.root_value_target;
+    d.v_mix = o.v_mix;
+    d.root_value_inference = o.root_value_inference;
+    d.entropy = o.entropy;
+    d.legal_action_max_entropy = o.legal_action_max_entropy;
+    d.root_entropy_value_target = o.root_entropy_value_target;
+    d.playout_policy = o.playout_policy;
+    d.playout_appended = o.playout_appended;
+    d.sims_run = o.sims_run;
+    d.status = o.status;
+    const NetOut init_out{init_logits, init_policy, init_value, 1, 0};
+    const NetOut step_out{sim_logits, sim_policy, sim_value, S, 1};
+    launch_root(ctx->stream, P, T, legal, to_play, num_simulations, ctx->cfg.search.num_simulations, init_out, gumbel,
+                dirichlet, Recording{});
+    for (int s = 0; s < steps; s++) {
+        launch_select(ctx->stream, P, T, pl.net_src, pl.net_dst, pl.net_action, pl.net_active);
+        launch_backup(ctx->stream, P, T, step_out, Recording{});
+    }
+    launch_finish(ctx->stream, P, T, exploration_time, u, d, nullptr);
+    HIP_TRY(hipGetLastError());
+    return 0;   // queued on the context's stream: mz_synchronize() before reading the outputs
 }
 
 int mz_set_recording(mz_ctx* ctx, int enable) {
