@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0}   # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "f16": 2500.0}   # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
 
 WORKLOADS = {
     # name: (spec factory name, n, m, c_visit, known bounds)   SURVEY.md §8a-0
@@ -100,7 +100,7 @@ def find_traffic(workload, precision, games):
                 t = json.load(f)
         except (OSError, ValueError):
             continue
-        if t.get("precision") != precision or "bytes_per_sample" not in t:
+        if t.get("precision") not in (precision, "bf16" if precision == "f16" else precision) or "bytes_per_sample" not in t:
             continue
         key = (t.get("games") == games, os.path.basename(path))
         if best is None or key > best[0]:
@@ -122,7 +122,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="go9", choices=sorted(WORKLOADS))
     ap.add_argument("--games", type=int, default=16384, help="concurrent games per GPU (SURVEY.md §8d: B in {1024, 4096, 16384})")
-    ap.add_argument("--precision", default="bf16", choices=["fp32", "bf16"])
+    ap.add_argument("--precision", default="f16", choices=["fp32", "bf16", "f16"],
+                    help="network arithmetic: fp32 exact kernels, or MFMA with bf16 / fp16 operands and fp32 accumulation")
     ap.add_argument("--cpu-games", type=int, default=1024, help="games in the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -140,7 +141,7 @@ def main():
     spec_name, n, m, c_visit, bounds = WORKLOADS[args.workload]
     spec = netspec.SPECS[spec_name]()
     B, A = args.games, spec.action_space
-    precision = capi.PRECISION_BF16 if args.precision == "bf16" else capi.PRECISION_FP32
+    precision = {"bf16": capi.PRECISION_BF16, "f16": capi.PRECISION_F16, "fp32": capi.PRECISION_FP32}[args.precision]
     ctx = capi.Context(capi.make_config(spec, n, m, c_visit, known_bounds=bounds, max_games=B, precision=precision,
                                         gumbel_seed=7 + 1000003 * rank),   # a stream of its own per shard
                        device=local_rank)

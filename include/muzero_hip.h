@@ -63,7 +63,10 @@ typedef struct mz_search_config {
     int32_t reserved0;
 } mz_search_config;
 
-enum { MZ_PRECISION_FP32 = 0, MZ_PRECISION_BF16 = 1 };
+/* Arithmetic of the network forward.  FP32: the reference's (exact fp32 kernels).  BF16 / F16: MFMA with 16-bit operands
+ * and fp32 accumulation; F16 operands carry an 11-bit significand (bf16: 8), i.e. 8x less rounding error at the same
+ * matrix rate - the default of bench.py; both are held to a stated tolerance against the fp32 forward. */
+enum { MZ_PRECISION_FP32 = 0, MZ_PRECISION_BF16 = 1, MZ_PRECISION_F16 = 2 };
 
 typedef struct mz_config {
     mz_net_config net;

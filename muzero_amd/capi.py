@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("MZ_LIB", os.path.join(_HERE, "libmuzero_hip.so"))  # 
 
 PRECISION_FP32 = 0
 PRECISION_BF16 = 1
+PRECISION_F16 = 2
 T_NAMES = ("initial", "recurrent", "tree_root", "tree_select", "tree_backup", "tree_finish")
 
 

@@ -85,7 +85,7 @@ struct mz_ctx {
     size_t w_f32_count = 0;
     NetProgramF32 prog_host{};
     NetProgramF32* prog_dev = nullptr;
-    MfmaNet* mfma = nullptr;        // packed bf16 weights + scratch for the MFMA path
+    MfmaAny* mfma = nullptr;        // packed bf16 / fp16 weights + scratch of the MFMA paths
     bool weights_loaded = false;
     int* action_cells = nullptr;    // [A]
     int* order_dev = nullptr;       // [A]
@@ -442,7 +442,7 @@ int pack_and_upload(mz_ctx* ctx, const std::vector<float>& blob) {
     }
     HIP_TRY(hipMemcpy(ctx->w_f32, dst.data(), dst.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ctx->prog_dev, &pr, sizeof(pr), hipMemcpyHostToDevice));
-    if (ctx->cfg.precision == MZ_PRECISION_BF16) {
+    if (ctx->cfg.precision != MZ_PRECISION_FP32) {
         std::string err;
         if (mfma_pack_weights(ctx->mfma, ctx->nd, blob.data(), blob.size(), &err) != 0) return ctx_fail(ctx, err);
     }
@@ -452,7 +452,7 @@ int pack_and_upload(mz_ctx* ctx, const std::vector<float>& blob) {
 
 int run_net(mz_ctx* ctx, bool initial, const NetIO& io) {
     TimerScope ts(ctx, initial ? MZ_T_INITIAL : MZ_T_RECURRENT);
-    if (ctx->cfg.precision == MZ_PRECISION_BF16) {
+    if (ctx->cfg.precision != MZ_PRECISION_FP32) {
         std::string err;
         if (mfma_forward(ctx->mfma, ctx->stream, initial, ctx->nd, io, &err) != 0) return ctx_fail(ctx, err);
     } else {
@@ -731,7 +731,7 @@ int mz_create(const mz_config* cfg, int device, mz_ctx** out) {
     if (n.height < 1 || n.width < 1 || n.height * n.width > 32767 / 9) return ctx_fail(nullptr, "bad board size");
     if (n.channels < 1 || n.bottleneck < 1 || n.obs_planes < 1 || n.action_planes < 1)
         return ctx_fail(nullptr, "bad channel counts");
-    if (cfg->precision != MZ_PRECISION_FP32 && cfg->precision != MZ_PRECISION_BF16)
+    if (cfg->precision != MZ_PRECISION_FP32 && cfg->precision != MZ_PRECISION_BF16 && cfg->precision != MZ_PRECISION_F16)
         return ctx_fail(nullptr, "unknown precision");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
@@ -835,9 +835,9 @@ int mz_create(const mz_config* cfg, int device, mz_ctx** out) {
     }
     ctx->n_params = count_params(d);
     if (dev_alloc(ctx, &ctx->w_master, ctx->n_params) || dev_alloc(ctx, &ctx->prog_dev, 1)) return fail("");
-    if (cfg->precision == MZ_PRECISION_BF16) {
+    if (cfg->precision != MZ_PRECISION_FP32) {
         std::string err;
-        ctx->mfma = mfma_create(d, (int)Bio, &err);
+        ctx->mfma = mfma_create(cfg->precision == MZ_PRECISION_F16, d, (int)Bio, &err);
         if (!ctx->mfma) return fail(err);
     }
     *out = ctx;
@@ -1098,8 +1098,8 @@ int mz_read_hidden(mz_ctx* ctx, int32_t slot, float* out) {
     const size_t n = (size_t)ctx->nd.C * ctx->nd.HW;
     const long long base = (long long)ctx->cfg.max_games * ctx->N;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    if (ctx->cfg.precision == MZ_PRECISION_BF16) {
-        // the MFMA path keeps a slot as [C/4][HW][4] (channel quads interleaved, net_mfma.hip x_load / x_store);
+    if (ctx->cfg.precision != MZ_PRECISION_FP32) {
+        // the MFMA paths keep a slot as [C/4][HW][4] (channel quads interleaved, net_mfma.hip x_load / x_store);
         // the caller gets the reference's [C][H][W]
         const int HW = ctx->nd.HW;
         std::vector<float> q(n), r(n);

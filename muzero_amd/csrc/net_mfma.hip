@@ -37,9 +37,32 @@
 // logits/policy/value out.
 //
 // Reference math: see net_fp32.hip / oracle/net.py (same citations).
+// This file is compiled twice (Makefile): -DMZ_F16=0 -> bf16 operands (8-bit significand, fp32's exponent range), and
+// -DMZ_F16=1 -> fp16 operands (11-bit significand: 8x smaller rounding error at the same matrix rate; the operands here
+// are LayerNorm outputs, [0, 1] hidden states, 0/1 planes and O(1) weights, far inside fp16's range, and gfx950's MFMA
+// keeps fp16 subnormals).  Everything else - tiling, LDS layout, fp32 accumulation, fp16 gamma/beta - is shared.
 #include "net_mfma.h"
 
 #include <math.h>
+
+#ifndef MZ_F16
+#define MZ_F16 0
+#endif
+#if MZ_F16
+#define MZ_IMPL impl_f16
+#define MfmaNet MfmaNetF16
+#define mfma_create mfma_create_f16
+#define mfma_destroy mfma_destroy_f16
+#define mfma_pack_weights mfma_pack_weights_f16
+#define mfma_forward mfma_forward_f16
+#else
+#define MZ_IMPL impl_bf16
+#define MfmaNet MfmaNetBf16
+#define mfma_create mfma_create_bf16
+#define mfma_destroy mfma_destroy_bf16
+#define mfma_pack_weights mfma_pack_weights_bf16
+#define mfma_forward mfma_forward_bf16
+#endif
 
 #include <cstdlib>
 #include <cstring>
@@ -47,10 +70,19 @@
 
 namespace mz {
 
-namespace {
+namespace MZ_IMPL {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+#if MZ_F16
+typedef _Float16 op_t;   // MFMA operand element
+#define MZ_CVT_PK "v_cvt_pk_f16_f32"
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+#else
+typedef __bf16 op_t;
+#define MZ_CVT_PK "v_cvt_pk_bf16_f32"
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+#endif
+typedef __attribute__((ext_vector_type(8))) op_t bf16x8;   // (the names predate the fp16 variant: 8 / 4 operand elements)
+typedef __attribute__((ext_vector_type(4))) op_t bf16x4;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -144,13 +176,13 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 __device__ __forceinline__ bf16x8 pack8(const float* y) {
     bf16x8 r;
 #pragma unroll
-    for (int i = 0; i < 8; i++) r[i] = (__bf16)y[i];
+    for (int i = 0; i < 8; i++) r[i] = (op_t)y[i];
     return r;
 }
 __device__ __forceinline__ bf16x4 pack4(const float* y) {
     bf16x4 r;
 #pragma unroll
-    for (int i = 0; i < 4; i++) r[i] = (__bf16)y[i];
+    for (int i = 0; i < 4; i++) r[i] = (op_t)y[i];
     return r;
 }
 
@@ -399,7 +431,7 @@ __device__ __forceinline__ void ln_apply_pk(const f32x16& v, float rstd, float n
             const float y0 = fmaf(t.x, (float)hv[e], (float)hv[4 + e]);
             const float y1 = fmaf(t.y, (float)hv[e + 1], (float)hv[4 + e + 1]);
             unsigned pk;
-            asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(y0), "v"(y1));
+            asm(MZ_CVT_PK " %0, %1, %2" : "=v"(pk) : "v"(y0), "v"(y1));
             s16x2 r = __builtin_elementwise_max(__builtin_bit_cast(s16x2, pk), (s16x2){0, 0});
             o[2 * qd + e / 2] = __builtin_bit_cast(unsigned, r);
         }
@@ -419,7 +451,6 @@ __device__ __forceinline__ void img_store(char* img, int rs, int col, int rt, in
         *reinterpret_cast<bf16x4*>(img + col * rs + (32 * rt + 8 * qd + 4 * h) * 2) = pack4(&y[4 * qd]);
 }
 
-#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
 // relu(LN(v)) of this wave's NR row tiles -> image rows of its own columns.  gb = this LayerNorm's table.
 // gtab != nullptr: the table was copied to LDS under the conv in front (gtab_issue) and is read from there.
@@ -1183,7 +1214,7 @@ __device__ __forceinline__ void bcast_body(Ctx& c, const Col (&k)[G::NC], const 
             const int padw = KP - c.HW;
             const int ch = i / (NB * padw), rem = i - ch * (NB * padw);
             const int bd = rem / padw, pp = rem - bd * padw;
-            *reinterpret_cast<__bf16*>(tb + ch * TBS + (bd * KP + c.HW + pp) * 2) = (__bf16)0.f;
+            *reinterpret_cast<op_t*>(tb + ch * TBS + (bd * KP + c.HW + pp) * 2) = (op_t)0.f;
         }
 #pragma unroll
         for (int ct = 0; ct < NC; ct++)
@@ -1196,7 +1227,7 @@ __device__ __forceinline__ void bcast_body(Ctx& c, const Col (&k)[G::NC], const 
 #pragma unroll
                     for (int i = 0; i < 16; i++) {
                         const int ch = 32 * (c.wr * NRCW + rt) + (i & 3) + 8 * (i >> 2) + 4 * c.h;
-                        *reinterpret_cast<__bf16*>(tb + ch * TBS + cbase * 2) = (__bf16)y[i];
+                        *reinterpret_cast<op_t*>(tb + ch * TBS + cbase * 2) = (op_t)y[i];
                     }
                 }
             }
@@ -1391,6 +1422,9 @@ inline unsigned short f2bf(float f) {
     u += 0x7fffu + ((u >> 16) & 1u);
     return (unsigned short)(u >> 16);
 }
+inline unsigned short f2h(float f);
+// fp32 -> MFMA operand element (round to nearest even)
+inline unsigned short f2op(float f) { return MZ_F16 ? f2h(f) : f2bf(f); }
 inline unsigned short f2h(float f) {
     _Float16 h = (_Float16)f;
     unsigned short u;
@@ -1406,7 +1440,7 @@ struct FragWriter {
         size_t base = out.size();
         out.resize(base + 512);
         for (int l = 0; l < 64; l++)
-            for (int j = 0; j < 8; j++) out[base + l * 8 + j] = f2bf(w(l & 31, 8 * (l >> 5) + j));
+            for (int j = 0; j < 8; j++) out[base + l * 8 + j] = f2op(w(l & 31, 8 * (l >> 5) + j));
     }
 };
 
@@ -1450,7 +1484,8 @@ struct TowerHost {
     TowerDev dev{};
 };
 
-}  // namespace
+}  // namespace MZ_IMPL
+using namespace MZ_IMPL;
 
 struct MfmaNet {
     NetDims d{};
@@ -1466,7 +1501,7 @@ struct MfmaNet {
     bool packed = false;
 };
 
-namespace {
+namespace MZ_IMPL {
 
 bool shape_supported(const NetDims& d) {
     const bool c128 = d.C == 128 && d.Cb == 64, c256 = d.C == 256 && d.Cb == 128;
@@ -1531,12 +1566,13 @@ int upload(MfmaNet* n, const std::vector<T>& v, const void** out, size_t slack_b
     return 0;
 }
 
-}  // namespace
+}  // namespace MZ_IMPL
+using namespace MZ_IMPL;
 
 MfmaNet* mfma_create(const NetDims& d, int max_batch, std::string* err) {
     if (!shape_supported(d)) {
         if (err)
-            *err = "bf16 MFMA path supports numChannels/numBottleneckChannels 128/64 and 256/128 on boards of 4..96 "
+            *err = "the MFMA paths (bf16 / fp16 operands) support numChannels/numBottleneckChannels 128/64 and 256/128 on boards of 4..96 "
                    "cells; use MZ_PRECISION_FP32 for other shapes";
         return nullptr;
     }
@@ -1655,7 +1691,7 @@ int mfma_pack_weights(MfmaNet* n, const NetDims& d, const float* blob, size_t co
                         for (int l = 0; l < 64; l++)
                             for (int j = 0; j < 8; j++) {
                                 const int q = 32 * qt + (l & 31), p = 16 * ks + 8 * (l >> 5) + j;
-                                T.wbf.push_back((q < HW && p < HW) ? f2bf(wb[(size_t)q * HW + p]) : 0);
+                                T.wbf.push_back((q < HW && p < HW) ? f2op(wb[(size_t)q * HW + p]) : 0);
                             }
             }
         }
@@ -1710,7 +1746,7 @@ int mfma_pack_weights(MfmaNet* n, const NetDims& d, const float* blob, size_t co
     return 0;
 }
 
-namespace {
+namespace MZ_IMPL {
 
 template <class G, int IN, int OUT>
 void launch_seg(MfmaNet* n, hipStream_t st, int grid, const NetDims& d, const TowerDev& tw, const NetIO& io, int b0,
@@ -1849,7 +1885,8 @@ int forward_t(MfmaNet* n, hipStream_t st, bool initial, const NetDims& d, const 
     return 0;
 }
 
-}  // namespace
+}  // namespace MZ_IMPL
+using namespace MZ_IMPL;
 
 int mfma_forward(MfmaNet* n, hipStream_t st, bool initial, const NetDims& d, const NetIO& io, std::string* err) {
     if (!n || !n->packed) {

@@ -21,8 +21,9 @@ CASES = {
 }
 
 
+@pytest.mark.parametrize("precision", [capi.PRECISION_BF16, capi.PRECISION_F16])
 @pytest.mark.parametrize("name", ["tictactoe", "go5", "pegsolitair"])
-def test_baseline_batch_properties_bf16(name):
+def test_baseline_batch_properties_mfma(name, precision):
     factory, nb_tile, k = CASES[name]
     spec = factory()
     c = H.SEARCH_CASES[name]
@@ -40,7 +41,7 @@ def test_baseline_batch_properties_bf16(name):
 
     def run(nb):
         ctx = capi.Context(capi.make_config(spec, n, m, c["c_visit"], known_bounds=c["bounds"], max_games=nb,
-                                            precision=capi.PRECISION_BF16))
+                                            precision=precision))
         ctx.load_weights(w)
         ctx.set_action_cells(netspec.action_cells_board(spec))
         out = ctx.search_moves(nb, obs[:nb], legal[:nb], to_play=to_play[:nb], gumbel=g[:nb])

@@ -49,10 +49,10 @@ def _e2e(spec, case, B, seed, precision=capi.PRECISION_FP32, frac=0.0):
     # the recorded root outputs are the network's: compare with the CPU forward
     ref = NetOracle(spec, w)
     _, r_lg, r_pol, r_val = ref.initial_inference(obs)
-    tol = 2e-4 if precision == capi.PRECISION_FP32 else 3e-2
+    tol = {capi.PRECISION_FP32: 2e-4, capi.PRECISION_BF16: 3e-2, capi.PRECISION_F16: 5e-3}[precision]
     np.testing.assert_allclose(rec["init_logits"], r_lg.numpy(), rtol=tol, atol=tol)
     np.testing.assert_allclose(rec["init_policy"], r_pol.numpy(), rtol=tol, atol=tol)
-    vtol = tol if precision == capi.PRECISION_FP32 else 8e-2
+    vtol = {capi.PRECISION_FP32: 2e-4, capi.PRECISION_BF16: 8e-2, capi.PRECISION_F16: 1e-2}[precision]
     np.testing.assert_allclose(rec["init_value"] / spec.value_scale, r_val.numpy() / spec.value_scale, rtol=vtol,
                                atol=vtol)
     ctx.close()
@@ -120,6 +120,14 @@ def test_end_to_end_tictactoe_bf16_mfma():
 def test_end_to_end_go5_bf16_mfma_dirichlet():
     # numChannels 256 with a broadcast block (5 boards per workgroup), root noise on
     _e2e(netspec.spec_go5(), "go5", B=11, seed=10, precision=capi.PRECISION_BF16, frac=0.25)
+
+
+def test_end_to_end_go9_f16_mfma():
+    _e2e(netspec.spec_go9(), "go9", B=20, seed=5, precision=capi.PRECISION_F16)
+
+
+def test_end_to_end_go5_f16_mfma_dirichlet():
+    _e2e(netspec.spec_go5(), "go5", B=11, seed=10, precision=capi.PRECISION_F16, frac=0.25)
 
 
 def test_single_game_and_one_legal_action_shortcut_bf16():

@@ -5,6 +5,7 @@ Tolerances (north_star: "network outputs must match the reference DJL forward wi
 fp32/bf16 tolerance"; the reference's own cross-backend precedent is allClose(1e-2, 1e-2),
 onnx/.../BlockTestHelper.java:36):
   fp32 path: |diff| <= 2e-4 + 2e-4*|ref| on hidden state, logits, policy; value/value_scale likewise.
+  fp16 path (MFMA, fp16 operands): 4e-3 on hidden, 5e-3 on logits, 3e-3 on policy, 1e-2 on value/value_scale.
   bf16 path: |diff| <= 3e-2 + 3e-2*|ref| on logits/hidden, 2e-2 on policy, 8e-2 on value/value_scale
   (mean |diff| of value/value_scale <= 2.5e-2).  The value head normalises ONE 81-cell channel per board
   (PredictionBlock.java:46-57), which amplifies the ~4e-3 bf16 error of the hidden state on random weights;
@@ -20,7 +21,9 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 
 TOL = {capi.PRECISION_FP32: dict(h=2e-4, l=2e-4, p=2e-4, v=2e-4),
-       capi.PRECISION_BF16: dict(h=3e-2, l=3e-2, p=2e-2, v=8e-2)}
+       capi.PRECISION_BF16: dict(h=3e-2, l=3e-2, p=2e-2, v=8e-2),
+       # fp16 operands: inside the reference's own cross-backend bar allClose(1e-2, 1e-2) on every output
+       capi.PRECISION_F16: dict(h=4e-3, l=5e-3, p=3e-3, v=1e-2)}
 
 
 def _specs():
@@ -108,6 +111,11 @@ def test_weight_blob_size_is_checked():
 def test_bf16_mfma_forward_matches_oracle(name):
     # B=7: two workgroup tiles for Go 9x9 (3 boards each) plus a ragged last tile
     _check(_specs()[name], capi.PRECISION_BF16, B=7, seed=3)
+
+
+@pytest.mark.parametrize("name", ["go9", "pegsolitair", "tictactoe", "go5"])
+def test_f16_mfma_forward_matches_oracle(name):
+    _check(_specs()[name], capi.PRECISION_F16, B=7, seed=3)
 
 
 @pytest.mark.parametrize("env,name", [({"MZ_FUSE": "0"}, "go9"), ({"MZ_FUSE": "1"}, "go9"),

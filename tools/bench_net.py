@@ -20,7 +20,7 @@ def main():
     args = ap.parse_args()
     spec = netspec.SPECS[args.workload]()
     B = args.games
-    prec = capi.PRECISION_BF16 if args.precision == "bf16" else capi.PRECISION_FP32
+    prec = {"bf16": capi.PRECISION_BF16, "f16": capi.PRECISION_F16, "fp32": capi.PRECISION_FP32}[args.precision]
     ctx = capi.Context(capi.make_config(spec, 4, 2, 50, max_games=1, precision=prec, pool_slots=2 * B))
     ctx.load_weights(netspec.pack_blob(spec, netspec.random_weights(spec, seed=1)))
     ctx.set_action_cells(netspec.action_cells_board(spec))
