@@ -92,7 +92,14 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) short s16x2;
 
 constexpr int MAXNB = 32;    // boards per workgroup upper bound (256 / 9 = 28)
-constexpr int ZROW_BYTES = 1024;
+// Zero rows that off-board 3x3 neighbours read.  One shared row would put every off-board lane of a ds_read_b128 on the
+// banks of some on-board lane of its 16-lane group (the 16 image rows of a group tile all 64 banks exactly): +1 LDS cycle
+// per group on most taps (PMC: SQ_LDS_BANK_CONFLICT was a sixth of SQ_LDS_IDX_ACTIVE, 58 % less with this).  Instead
+// there are 16 zero rows at the image's row stride, starting at the image's phase (mod 256 B): a lane reads zero row
+// (row index mod 16), which lies on the very banks its on-board read would have used (16 * RS is a multiple of 256 B
+// for every RS = 2C + 16).  Served that way: the bottleneck images (row stride 2 Cb + 16: the 3x3 convs c2 / c3, two
+// thirds of all MFMAs); the wider images of conv0 read zero row 0 only.  LdsPlan::zbytes = ZROWS * (2 Cb + 16).
+constexpr int ZROWS = 16;
 
 #if defined(MZ_STAMPS)  // diagnostic build: per-phase cycle counts of workgroup 0 (waves 0 and 7), printed by the kernel
 #define STAMP(c, i) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); (c).st_acc[i] += (unsigned)(t_ - (c).st_last); (c).st_last = t_; } while (0)
@@ -135,7 +142,7 @@ struct HeadDev {
 };
 // Byte offsets into the workgroup's one dynamic LDS array.
 struct LdsPlan {
-    int img_off, zrow_off, ring_off, tb_off, stat_off, meta_off, head_off, total;
+    int img_off, zrow_off, zbytes, ring_off, tb_off, stat_off, meta_off, head_off, total;
     int tbs;  // TB row stride in bytes (broadcast kernel)
     int kp, qt;
 };
@@ -519,7 +526,9 @@ __device__ __forceinline__ void conv_lds(Ctx& c, const Col (&k)[G::NC], WRing<G:
             const char* row;
             if (TAPS == 9) {
                 const int d = (t / 3 - 1) * c.Wd + (t % 3 - 1);
-                row = ((k[ct].nbmask >> t) & 1u) ? img + (k[ct].col + d) * RS : zrow;
+                const int v = k[ct].col + d;
+                row = ((k[ct].nbmask >> t) & 1u) ? img + v * RS
+                                                 : zrow + (RS == G::CB * 2 + 16 ? ((v + 16 * ZROWS) & (ZROWS - 1)) * RS : 0);
             } else {
                 row = img + k[ct].col * RS;
             }
@@ -731,8 +740,8 @@ __device__ __forceinline__ bool setup(const NetDims& d, const NetIO& io, int NB,
         c.meta[2 * MAXNB + tid] = ok ? 1 : 0;
         c.meta[3 * MAXNB + tid] = (ok && IN == IN_HIDDEN) ? io.action_cells[io.action[g]] : -1;
     }
-    // the zero row that off-board 3x3 neighbours read
-    if (tid < ZROW_BYTES / 16) reinterpret_cast<u32x4*>(c.smem + c.L.zrow_off)[tid] = (u32x4){0, 0, 0, 0};
+    // the zero rows that off-board 3x3 neighbours read
+    for (int i = tid; i < c.L.zbytes / 16; i += blockDim.x) reinterpret_cast<u32x4*>(c.smem + c.L.zrow_off)[i] = (u32x4){0, 0, 0, 0};
     lds_barrier();
     int any = 0;
     for (int b = 0; b < NB; b++) any |= c.meta[2 * MAXNB + b];
@@ -1510,10 +1519,13 @@ bool shape_supported(const NetDims& d) {
 
 int align16(int x) { return (x + 15) / 16 * 16; }
 
-void plan_tail(LdsPlan& L, int end, int NW) {
+void plan_tail(LdsPlan& L, int end, int NW, int Cb) {
     end = align16(end);
+    while ((end - L.img_off) % 256) end += 16;   // zero rows start at the image's bank phase
     L.zrow_off = end;
-    end += ZROW_BYTES;
+    L.zbytes = ZROWS * (2 * Cb + 16);
+    if (L.zbytes < 1024) L.zbytes = 1024;        // conv0 reads up to (C + 16) * 2 + 16 bytes of zero row 0
+    end += L.zbytes;
     L.stat_off = end;
     end += (2 * MAXNB * NW * 2 + 2 * 256 + 2 * MAXNB) * 4;  // wpart x2, ipart, bstat
     L.meta_off = end;
@@ -1530,7 +1542,7 @@ LdsPlan make_plan_seg(const NetDims& d, int COLS, int NW, int SM) {
     L.img_off = NSLOT * SM * 1024;
     int end = L.img_off + align16(COLS * rs0);
     L.head_off = 0;
-    plan_tail(L, end, NW);
+    plan_tail(L, end, NW, d.Cb);
     return L;
 }
 // k_bcast: [region 2 = ring / TB][image, C channels]
@@ -1544,7 +1556,7 @@ LdsPlan make_plan_bcast(const NetDims& d, int COLS, int NB, int NW, int SM, bool
     L.ring_off = 0;
     L.tb_off = 0;
     L.img_off = ring > tbb ? ring : tbb;
-    plan_tail(L, L.img_off + align16(COLS * rsc), NW);
+    plan_tail(L, L.img_off + align16(COLS * rsc), NW, d.Cb);
     return L;
 }
 
@@ -1808,6 +1820,16 @@ template <class G>
 int forward_t(MfmaNet* n, hipStream_t st, bool initial, const NetDims& d, const NetIO& io) {
     const int grid = (io.B + n->NB - 1) / n->NB;
     const TowerDev& tw = n->tw[initial ? 0 : 1];
+#if defined(MZ_FAST_BUILD)   // experiment builds (tools/fastlib.sh): only the one-launch Go 9x9 tower is instantiated
+    {
+        int e = 0;
+        while (e < d.R && tw.type[e] == 0) e++;
+        if (initial) launch_tower<G, IN_OBS, 6>(n, st, grid, d, tw, io, e);
+        else launch_tower<G, IN_HIDDEN, 6>(n, st, grid, d, tw, io, e);
+        hipLaunchKernelGGL(k_heads, dim3((io.B + HS - 1) / HS), dim3(HT), heads_lds_bytes(d), st, d, n->hd, io);
+        return 0;
+    }
+#else
     // MZ_FUSE=0: every broadcast block as its own launch (k_bcast); MZ_FUSE=1: fused with the blocks behind it (k_bseg);
     // default: that, and the whole tower as one launch (k_tower) where it holds a single broadcast block
     const bool fuse = n->fuse != 0;
@@ -1883,6 +1905,7 @@ int forward_t(MfmaNet* n, hipStream_t st, bool initial, const NetDims& d, const 
         b = e + 1;
     }
     return 0;
+#endif
 }
 
 }  // namespace MZ_IMPL
@@ -1898,11 +1921,15 @@ int mfma_forward(MfmaNet* n, hipStream_t st, bool initial, const NetDims& d, con
         return -1;
     }
     int rc;
+#if defined(MZ_FAST_BUILD)
+    rc = forward_t<Geo<128, 64, 1, 8, 24, 2>>(n, st, initial, d, io);
+#else
     switch (n->geom) {
         case 0: rc = forward_t<Geo<128, 64, 1, 8, 24, 2>>(n, st, initial, d, io); break;
         case 1: rc = forward_t<Geo<256, 128, 2, 8, 24, 2>>(n, st, initial, d, io); break;
         default: rc = forward_t<Geo<128, 64, 1, 4, 24, 1, 2>>(n, st, initial, d, io); break;
     }
+#endif
     if (hipError_t e = take_optin_error()) {
         if (err) *err = std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(e);
         return -1;
