@@ -189,10 +189,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    ctx.set_timing(True)
     sims_total = 0
-    kernel_ms = {k: 0.0 for k in capi.T_NAMES}
-    kernel_launches = {k: 0 for k in capi.T_NAMES}
     path_sum = 0.0
     sync()
     t0 = time.perf_counter()
@@ -201,12 +198,32 @@ def main():
         s, mp = ctx.last_stats()
         sims_total += s
         path_sum += mp * s
+    sync()
+    dt = time.perf_counter() - t0
+    assert int(outs["status"].abs().sum().item()) == 0
+
+    # Per-kernel device times for the roofline (HIP events on the library's own stream).  The timed region above runs a
+    # move as the product does: the two halves of the batch on two streams, one half's tree / head kernels under the
+    # other half's tower - kernel durations overlap there and cannot be attributed.  So the same move is run
+    # `steps` more times right here with every kernel back to back on ONE stream (mz_set_stream_split(0): undivided,
+    # non-overlapping launches, identical results) and those launches are timed; `serial_ms_per_step` is that mode's
+    # wall time per step.  rocprofv3 of `MZ_STREAMS=1 python bench.py` sees the same launches (profiles/).
+    ctx.set_stream_split(False)
+    ctx.set_timing(True)
+    kernel_ms = {k: 0.0 for k in capi.T_NAMES}
+    kernel_launches = {k: 0 for k in capi.T_NAMES}
+    step()
+    sync()
+    t1 = time.perf_counter()
+    for k in range(args.steps):
+        step()
         for name, (ms, cnt) in ctx.get_timing().items():
             kernel_ms[name] += ms
             kernel_launches[name] += cnt
     sync()
-    dt = time.perf_counter() - t0
-    assert int(outs["status"].abs().sum().item()) == 0
+    serial_dt = time.perf_counter() - t1
+    ctx.set_timing(False)
+    ctx.set_stream_split(True)
 
     # whole-job aggregate: MAX time over ranks, SUM of simulations (episode statistics gathered over RCCL)
     if comm is not None:
@@ -247,7 +264,11 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "recurrentInference", "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
                          "kernels": "k_tower(conv0 + blocks + broadcast block + blocks + rescale + head convs) -> k_heads",
-                         "flops_per_launch": fl["recurrent"] * B, "avg_launch_ms": rec_ms / rec_n},
+                         "flops_per_launch": fl["recurrent"] * B, "avg_launch_ms": rec_ms / rec_n,
+                         "launches_timed": rec_n,
+                         "measured": "HIP events around every recurrentInference launch of `steps` further moves run "
+                                     "on one stream (mz_set_stream_split(0)) right after the timed region"},
+            "serial_ms_per_step": serial_dt / args.steps * 1e3,
             "tree_kernels": {"bound": "hbm", "mean_path_len": mean_path, "algorithmic_bytes_per_sim": tree_bytes,
                              "achieved_GBps": (tree_bytes * sims_total / (tree_ms / 1e3) / 1e9) if tree_ms else None,
                              "peak_GBps": 8000.0},

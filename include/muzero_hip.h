@@ -214,6 +214,11 @@ int mz_tree_minmax(mz_ctx* ctx, int game, double* minimum, double* maximum);
 enum { MZ_T_INITIAL = 0, MZ_T_RECURRENT = 1, MZ_T_TREE_ROOT = 2, MZ_T_TREE_SELECT = 3, MZ_T_TREE_BACKUP = 4,
        MZ_T_TREE_FINISH = 5, MZ_T_COUNT = 6 };
 int mz_set_timing(mz_ctx* ctx, int enable);
+/* mz_search_moves runs the simulation steps of the two halves of a large batch on two HIP streams (default, enable = 1),
+ * so that one half's tree and head kernels run under the other half's tower; results are bit-identical either way.
+ * enable = 0 runs every kernel of a move back to back on one stream: per-kernel times (mz_get_timing, rocprofv3) are
+ * then those of undivided, non-overlapping launches - what a roofline figure needs. */
+int mz_set_stream_split(mz_ctx* ctx, int enable);
 int mz_get_timing(mz_ctx* ctx, double* ms /* [MZ_T_COUNT] */, int64_t* launches /* [MZ_T_COUNT] */);
 /* Total simulations run / mean search-path length (nodes incl. root) of the last mz_search_moves call. */
 int mz_get_last_stats(mz_ctx* ctx, int64_t* simulations, double* mean_path_len);

@@ -54,7 +54,7 @@ EXPORTS = (
     "mz_tree_num_nodes", "mz_tree_node", "mz_tree_minmax", "mz_set_timing", "mz_get_timing", "mz_get_last_stats",
     "mz_synchronize", "mz_version", "mz_comm_unique_id", "mz_comm_init", "mz_comm_destroy", "mz_broadcast_weights",
     "mz_gather_stats", "mz_comm_barrier", "mz_get_recording_games", "mz_get_gumbel", "mz_seed_gumbel",
-    "mz_child_order", "mz_noalloc_scratch_bytes", "mz_search_moves_injected_noalloc")
+    "mz_child_order", "mz_noalloc_scratch_bytes", "mz_search_moves_injected_noalloc", "mz_set_stream_split")
 NOALLOC_SCRATCH_BYTES = 16 << 20
 COMM_ID_BYTES = 128
 
@@ -105,6 +105,7 @@ def lib():
         L.mz_get_gumbel.argtypes = [vp, vp]
         L.mz_seed_gumbel.argtypes = [vp, C.c_uint64, C.c_uint64]
         L.mz_child_order.argtypes = [vp, C.c_int, vp]
+        L.mz_set_stream_split.argtypes = [vp, C.c_int]
         L.mz_noalloc_scratch_bytes.argtypes = [vp, C.c_int]
         L.mz_noalloc_scratch_bytes.restype = C.c_size_t
         L.mz_search_moves_injected_noalloc.argtypes = L.mz_search_moves_injected.argtypes
@@ -394,6 +395,9 @@ class Context:
     # --- measurement ------------------------------------------------------------------------------
     def set_timing(self, enable):
         self._check(lib().mz_set_timing(self._h, 1 if enable else 0))
+
+    def set_stream_split(self, enable):
+        self._check(lib().mz_set_stream_split(self._h, 1 if enable else 0))
 
     def get_timing(self):
         ms = np.zeros(len(T_NAMES), np.float64)

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -71,6 +72,12 @@ struct mz_ctx {
     mz_config cfg{};
     int device = 0;
     hipStream_t stream = nullptr;
+    // second stream: mz_search_moves runs the simulation steps of the two halves of the batch on two streams, so that
+    // the tree kernels and the head kernel of one half run under the tower of the other (and the ragged last round of
+    // workgroups of one tower under the first round of the next)
+    hipStream_t stream_b = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool split_streams = true;
     std::string error;
     NetDims nd{};
     TreeParams tp{};
@@ -229,8 +236,9 @@ std::vector<int> hashmap_order_all(int A) {
 struct TimerScope {
     mz_ctx* ctx;
     int kind;
+    hipStream_t st;
     size_t idx = (size_t)-1;
-    TimerScope(mz_ctx* c, int k) : ctx(c), kind(k) {
+    TimerScope(mz_ctx* c, int k, hipStream_t s = nullptr) : ctx(c), kind(k), st(s ? s : c->stream) {
         if (!ctx->timing) return;
         if (ctx->events_used == ctx->events.size()) {
             EventPair ep;
@@ -240,10 +248,10 @@ struct TimerScope {
         }
         idx = ctx->events_used++;
         ctx->events[idx].kind = kind;
-        (void)hipEventRecord(ctx->events[idx].a, ctx->stream);
+        (void)hipEventRecord(ctx->events[idx].a, st);
     }
     ~TimerScope() {
-        if (idx != (size_t)-1) (void)hipEventRecord(ctx->events[idx].b, ctx->stream);
+        if (idx != (size_t)-1) (void)hipEventRecord(ctx->events[idx].b, st);
     }
 };
 
@@ -257,6 +265,7 @@ void timing_begin(mz_ctx* ctx) {
 void timing_end(mz_ctx* ctx) {
     if (!ctx->timing) return;
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream_b) (void)hipStreamSynchronize(ctx->stream_b);
     for (size_t i = 0; i < ctx->events_used; i++) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, ctx->events[i].a, ctx->events[i].b) == hipSuccess) {
@@ -450,13 +459,14 @@ int pack_and_upload(mz_ctx* ctx, const std::vector<float>& blob) {
     return 0;
 }
 
-int run_net(mz_ctx* ctx, bool initial, const NetIO& io) {
-    TimerScope ts(ctx, initial ? MZ_T_INITIAL : MZ_T_RECURRENT);
+int run_net(mz_ctx* ctx, bool initial, const NetIO& io, hipStream_t st = nullptr) {
+    if (!st) st = ctx->stream;
+    TimerScope ts(ctx, initial ? MZ_T_INITIAL : MZ_T_RECURRENT, st);
     if (ctx->cfg.precision != MZ_PRECISION_FP32) {
         std::string err;
-        if (mfma_forward(ctx->mfma, ctx->stream, initial, ctx->nd, io, &err) != 0) return ctx_fail(ctx, err);
+        if (mfma_forward(ctx->mfma, st, initial, ctx->nd, io, &err) != 0) return ctx_fail(ctx, err);
     } else {
-        if (hipError_t e = launch_net_fp32(ctx->stream, initial, ctx->nd, ctx->prog_dev, ctx->w_f32, io))
+        if (hipError_t e = launch_net_fp32(st, initial, ctx->nd, ctx->prog_dev, ctx->w_f32, io))
             return ctx_fail(ctx, std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(e));
     }
     return 0;
@@ -625,29 +635,52 @@ int search_impl(mz_ctx* ctx, int B, const float* obs, const uint8_t* legal, cons
         launch_root(ctx->stream, P, ctx->ts, (const uint8_t*)d_legal, (const uint8_t*)d_toplay, (const int*)d_nsims,
                     ctx->cfg.search.num_simulations, init_out, (const double*)d_gumbel, (const double*)d_dir, ctx->rec);
     }
+    // Two half batches on two streams (real networks only; the cut is a multiple of the boards per workgroup tile, so
+    // every game keeps its place in its tile and results are those of the undivided batch bit for bit).  Games are
+    // independent units: the halves share nothing but the read-only weights.
+    int cut = B;
+    if (!injected && ctx->split_streams && ctx->stream_b) {
+        const int tile = ctx->mfma ? mfma_tile_boards(ctx->mfma) : 1;
+        const int half = (B / 2) / tile * tile;
+        if (half >= 64 * tile) cut = half;   // small batches: one stream (nothing to hide, two launch chains to pay)
+    }
+    const int nhalves = cut < B ? 2 : 1;
+    if (nhalves == 2) {
+        HIP_TRY(hipEventRecord(ctx->ev_fork, ctx->stream));
+        HIP_TRY(hipStreamWaitEvent(ctx->stream_b, ctx->ev_fork, 0));
+    }
     for (int s = 0; s < steps; s++) {
-        {
-            TimerScope ts(ctx, MZ_T_TREE_SELECT);
-            launch_select(ctx->stream, P, ctx->ts, ctx->net_src, ctx->net_dst, ctx->net_action, ctx->net_active);
+        for (int h = 0; h < nhalves; h++) {
+            hipStream_t st = h == 0 ? ctx->stream : ctx->stream_b;
+            const int g0 = h == 0 ? 0 : cut, cnt = nhalves == 1 ? B : (h == 0 ? cut : B - cut);
+            {
+                TimerScope ts(ctx, MZ_T_TREE_SELECT, st);
+                launch_select(st, P, ctx->ts, ctx->net_src, ctx->net_dst, ctx->net_action, ctx->net_active, g0, cnt);
+            }
+            if (!injected) {
+                NetIO io{};
+                io.B = cnt;
+                io.g_base = g0;
+                io.pool = ctx->pool;
+                io.src_slot = ctx->net_src + g0;
+                io.dst_slot = ctx->net_dst + g0;
+                io.action = ctx->net_action + g0;
+                io.active = ctx->net_active + g0;
+                io.action_cells = ctx->action_cells;
+                io.logits = ctx->net_logits + (size_t)g0 * A;
+                io.policy = ctx->net_policy + (size_t)g0 * A;
+                io.value = ctx->net_value + g0;
+                if (run_net(ctx, false, io, st)) return -1;
+            }
+            {
+                TimerScope ts(ctx, MZ_T_TREE_BACKUP, st);
+                launch_backup(st, P, ctx->ts, step_out, ctx->rec, g0, cnt);
+            }
         }
-        if (!injected) {
-            NetIO io{};
-            io.B = B;
-            io.pool = ctx->pool;
-            io.src_slot = ctx->net_src;
-            io.dst_slot = ctx->net_dst;
-            io.action = ctx->net_action;
-            io.active = ctx->net_active;
-            io.action_cells = ctx->action_cells;
-            io.logits = ctx->net_logits;
-            io.policy = ctx->net_policy;
-            io.value = ctx->net_value;
-            if (run_net(ctx, false, io)) return -1;
-        }
-        {
-            TimerScope ts(ctx, MZ_T_TREE_BACKUP);
-            launch_backup(ctx->stream, P, ctx->ts, step_out, ctx->rec);
-        }
+    }
+    if (nhalves == 2) {
+        HIP_TRY(hipEventRecord(ctx->ev_join, ctx->stream_b));
+        HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     }
     {
         TimerScope ts(ctx, MZ_T_TREE_FINISH);
@@ -748,6 +781,11 @@ int mz_create(const mz_config* cfg, int device, mz_ctx** out) {
     };
     if (hipSetDevice(device) != hipSuccess) return fail("hipSetDevice failed");
     if (hipStreamCreate(&ctx->stream) != hipSuccess) return fail("hipStreamCreate failed");
+    if (hipStreamCreate(&ctx->stream_b) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess)
+        return fail("hipStreamCreate / hipEventCreate failed");
+    if (const char* e = std::getenv("MZ_STREAMS")) ctx->split_streams = std::atoi(e) != 1;   // MZ_STREAMS=1: A/B runs
     if (hipError_t e = resolve_scratch(device))
         return fail(std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
 
@@ -788,6 +826,7 @@ int mz_create(const mz_config* cfg, int device, mz_ctx** out) {
     P.temp_root = cfg->search.temperature_root;
     P.device_gumbel = 0;
     P.gumbel_seed = P.gumbel_move = 0;
+    P.g0 = 0;
     ctx->gumbel_seed = cfg->search.gumbel_seed;
 
     TreeStore& T = ctx->ts;
@@ -848,6 +887,7 @@ void mz_destroy(mz_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream_b) (void)hipStreamSynchronize(ctx->stream_b);
     for (void* p : ctx->allocs) (void)hipFree(p);
     for (auto& b : ctx->stage)
         if (b.p) (void)hipFree(b.p);
@@ -861,6 +901,9 @@ void mz_destroy(mz_ctx* ctx) {
         (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
     }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->stream_b) (void)hipStreamDestroy(ctx->stream_b);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -1392,6 +1435,12 @@ int mz_tree_minmax(mz_ctx* ctx, int game, double* minimum, double* maximum) {
 int mz_set_timing(mz_ctx* ctx, int enable) {
     if (!ctx) return -1;
     ctx->timing = enable != 0;
+    return 0;
+}
+
+int mz_set_stream_split(mz_ctx* ctx, int enable) {
+    if (!ctx) return -1;
+    ctx->split_streams = enable != 0;
     return 0;
 }
 

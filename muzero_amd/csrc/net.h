@@ -48,6 +48,7 @@ struct NetIO {
     float* policy;            // [B][A]
     double* value;            // [B]
     int B;
+    int g_base;               // position of sample 0 in the context's per-sample scratch (two half batches in flight at once)
 };
 
 // Opt a kernel in to > 64 KiB of dynamic LDS.  hipFuncSetAttribute applies to the function on the CURRENT device, so

@@ -14,7 +14,8 @@ namespace mz {
     NET* mfma_create_##SUF(const NetDims& d, int max_batch, std::string* err);                                       \
     void mfma_destroy_##SUF(NET* n);                                                                                 \
     int mfma_pack_weights_##SUF(NET* n, const NetDims& d, const float* blob, size_t count, std::string* err);        \
-    int mfma_forward_##SUF(NET* n, hipStream_t st, bool initial, const NetDims& d, const NetIO& io, std::string* err);
+    int mfma_forward_##SUF(NET* n, hipStream_t st, bool initial, const NetDims& d, const NetIO& io, std::string* err);  \
+    int mfma_tile_boards_##SUF(const NET* n);
 MZ_DECLARE_MFMA(bf16, MfmaNetBf16)
 MZ_DECLARE_MFMA(f16, MfmaNetF16)
 #undef MZ_DECLARE_MFMA
@@ -45,6 +46,8 @@ inline void mfma_destroy(MfmaAny* a) {
 inline int mfma_pack_weights(MfmaAny* a, const NetDims& d, const float* blob, size_t count, std::string* err) {
     return a->f16 ? mfma_pack_weights_f16(a->h, d, blob, count, err) : mfma_pack_weights_bf16(a->b, d, blob, count, err);
 }
+// boards one workgroup tile carries: a batch cut at a multiple of it keeps every game's place in its tile
+inline int mfma_tile_boards(const MfmaAny* a) { return a->f16 ? mfma_tile_boards_f16(a->h) : mfma_tile_boards_bf16(a->b); }
 inline int mfma_forward(MfmaAny* a, hipStream_t st, bool initial, const NetDims& d, const NetIO& io, std::string* err) {
     return a->f16 ? mfma_forward_f16(a->h, st, initial, d, io, err) : mfma_forward_bf16(a->b, st, initial, d, io, err);
 }

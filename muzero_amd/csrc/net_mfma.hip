@@ -55,6 +55,7 @@
 #define mfma_destroy mfma_destroy_f16
 #define mfma_pack_weights mfma_pack_weights_f16
 #define mfma_forward mfma_forward_f16
+#define mfma_tile_boards mfma_tile_boards_f16
 #else
 #define MZ_IMPL impl_bf16
 #define MfmaNet MfmaNetBf16
@@ -62,6 +63,7 @@
 #define mfma_destroy mfma_destroy_bf16
 #define mfma_pack_weights mfma_pack_weights_bf16
 #define mfma_forward mfma_forward_bf16
+#define mfma_tile_boards mfma_tile_boards_bf16
 #endif
 
 #include <cstdlib>
@@ -142,7 +144,7 @@ struct HeadDev {
 };
 // Byte offsets into the workgroup's one dynamic LDS array.
 struct LdsPlan {
-    int img_off, zrow_off, zbytes, ring_off, tb_off, stat_off, meta_off, head_off, total;
+    int img_off, zrow_off, zbytes, zstride, ring_off, tb_off, stat_off, meta_off, head_off, total;
     int tbs;  // TB row stride in bytes (broadcast kernel)
     int kp, qt;
 };
@@ -528,7 +530,7 @@ __device__ __forceinline__ void conv_lds(Ctx& c, const Col (&k)[G::NC], WRing<G:
                 const int d = (t / 3 - 1) * c.Wd + (t % 3 - 1);
                 const int v = k[ct].col + d;
                 row = ((k[ct].nbmask >> t) & 1u) ? img + v * RS
-                                                 : zrow + (RS == G::CB * 2 + 16 ? ((v + 16 * ZROWS) & (ZROWS - 1)) * RS : 0);
+                                                 : zrow + (RS == G::CB * 2 + 16 ? ((v + 16 * ZROWS) & (ZROWS - 1)) * c.L.zstride : 0);
             } else {
                 row = img + k[ct].col * RS;
             }
@@ -924,7 +926,7 @@ __device__ __forceinline__ void seg_rest(Ctx& c, const Col (&k)[G::NC], const Ne
 #pragma unroll
             for (int ct = 0; ct < NC; ct++) {
                 if (!k[ct].live) continue;
-                float* dst = hd.hfeat + ((long long)(g0 + k[ct].board) * 3) * HW + k[ct].p;
+                float* dst = hd.hfeat + ((long long)(io.g_base + g0 + k[ct].board) * 3) * HW + k[ct].p;
 #pragma unroll
                 for (int o = 0; o < 3; o++) {
                     float sum = 0.f;
@@ -1079,7 +1081,7 @@ __global__ __launch_bounds__(HT) void k_heads(NetDims d, HeadDev hd, NetIO io) {
         float a00 = 0.f, a01 = 0.f, a02 = 0.f, a10 = 0.f, a11 = 0.f, a12 = 0.f;
         const bool v0 = lane < HW, v1 = lane + 64 < HW;
         if (live) {
-            const float* hf = hd.hfeat + (long long)g * 3 * HW;   // written by k_seg<.., OUT_FINAL>
+            const float* hf = hd.hfeat + (long long)(io.g_base + g) * 3 * HW;   // written by k_seg<.., OUT_FINAL>
             if (v0) {
                 a00 = hf[lane];
                 a01 = hf[HW + lane];
@@ -1523,8 +1525,14 @@ void plan_tail(LdsPlan& L, int end, int NW, int Cb) {
     end = align16(end);
     while ((end - L.img_off) % 256) end += 16;   // zero rows start at the image's bank phase
     L.zrow_off = end;
-    L.zbytes = ZROWS * (2 * Cb + 16);
+    const int rest = (2 * MAXNB * NW * 2 + 2 * 256 + 2 * MAXNB) * 4 + 4 * MAXNB * 4 + 16;
+    L.zstride = 2 * Cb + 16;
+    L.zbytes = ZROWS * L.zstride;
     if (L.zbytes < 1024) L.zbytes = 1024;        // conv0 reads up to (C + 16) * 2 + 16 bytes of zero row 0
+    if (end + L.zbytes + rest > 160 * 1024) {    // no room for 16 rows (Go 5x5's broadcast plan): one shared zero row
+        L.zstride = 0;
+        L.zbytes = 1024;
+    }
     end += L.zbytes;
     L.stat_off = end;
     end += (2 * MAXNB * NW * 2 + 2 * 256 + 2 * MAXNB) * 4;  // wpart x2, ipart, bstat
@@ -1911,12 +1919,14 @@ int forward_t(MfmaNet* n, hipStream_t st, bool initial, const NetDims& d, const 
 }  // namespace MZ_IMPL
 using namespace MZ_IMPL;
 
+int mfma_tile_boards(const MfmaNet* n) { return n ? n->NB : 1; }
+
 int mfma_forward(MfmaNet* n, hipStream_t st, bool initial, const NetDims& d, const NetIO& io, std::string* err) {
     if (!n || !n->packed) {
         if (err) *err = "mfma weights not packed";
         return -1;
     }
-    if (io.B > n->max_batch) {
+    if (io.g_base < 0 || io.B + io.g_base > n->max_batch) {
         if (err) *err = "batch exceeds the context's inference capacity";
         return -1;
     }

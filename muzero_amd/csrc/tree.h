@@ -18,6 +18,7 @@ struct TreeParams {
     // counter = (action, game, move counter)
     int device_gumbel;
     unsigned long long gumbel_seed, gumbel_move;
+    int g0;   // first game of this launch (k_select / k_backup run on half batches: grid = games of the half)
 };
 
 // Per-game scalars (array of structs; one wave touches one entry).
@@ -104,9 +105,11 @@ struct DeviceMoveOutputs {
 void launch_root(hipStream_t st, const TreeParams& P, const TreeStore& T, const uint8_t* legal, const uint8_t* to_play,
                  const int* nsims, int n_default, NetOut init, const double* gumbel, const double* dirichlet,
                  Recording rec);
+// count games starting at game g0 (arrays are indexed by the absolute game)
 void launch_select(hipStream_t st, const TreeParams& P, const TreeStore& T, int* net_src, int* net_dst, int* net_action,
-                   int* net_active);
-void launch_backup(hipStream_t st, const TreeParams& P, const TreeStore& T, NetOut out, Recording rec);
+                   int* net_active, int g0 = 0, int count = -1);
+void launch_backup(hipStream_t st, const TreeParams& P, const TreeStore& T, NetOut out, Recording rec, int g0 = 0,
+                   int count = -1);
 void launch_finish(hipStream_t st, const TreeParams& P, const TreeStore& T, const uint8_t* exploration_time,
                    const double* u, DeviceMoveOutputs o, unsigned long long* stats);
 

@@ -454,7 +454,7 @@ __global__ __launch_bounds__(W) void k_root(TreeParams P, TreeStore T, const uin
 __global__ __launch_bounds__(W) void k_select(TreeParams P, TreeStore T, int* __restrict__ net_src,
                                               int* __restrict__ net_dst, int* __restrict__ net_action,
                                               int* __restrict__ net_active) {
-    const int g = blockIdx.x, lane = threadIdx.x, A = P.A;
+    const int g = blockIdx.x + P.g0, lane = threadIdx.x, A = P.A;
     const long long gn = (long long)g * P.N;
     GameState* S = &T.gs[g];
     if (S->finished) {
@@ -526,7 +526,7 @@ __global__ __launch_bounds__(W) void k_select(TreeParams P, TreeStore T, int* __
 // gumbelActionsOnPhaseChange :153-166 / getLogitsAndQs :193-224)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(W) void k_backup(TreeParams P, TreeStore T, NetOut out, Recording rec) {
-    const int g = blockIdx.x, lane = threadIdx.x, A = P.A;
+    const int g = blockIdx.x + P.g0, lane = threadIdx.x, A = P.A;
     const long long gn = (long long)g * P.N;
     GameState* S = &T.gs[g];
     if (!S->active) return;
@@ -910,11 +910,16 @@ void launch_root(hipStream_t st, const TreeParams& P, const TreeStore& T, const 
                        dirichlet, rec);
 }
 void launch_select(hipStream_t st, const TreeParams& P, const TreeStore& T, int* net_src, int* net_dst, int* net_action,
-                   int* net_active) {
-    hipLaunchKernelGGL(k_select, dim3(P.B), dim3(W), 0, st, P, T, net_src, net_dst, net_action, net_active);
+                   int* net_active, int g0, int count) {
+    TreeParams Q = P;
+    Q.g0 = g0;
+    hipLaunchKernelGGL(k_select, dim3(count < 0 ? P.B : count), dim3(W), 0, st, Q, T, net_src, net_dst, net_action,
+                       net_active);
 }
-void launch_backup(hipStream_t st, const TreeParams& P, const TreeStore& T, NetOut out, Recording rec) {
-    hipLaunchKernelGGL(k_backup, dim3(P.B), dim3(W), 0, st, P, T, out, rec);
+void launch_backup(hipStream_t st, const TreeParams& P, const TreeStore& T, NetOut out, Recording rec, int g0, int count) {
+    TreeParams Q = P;
+    Q.g0 = g0;
+    hipLaunchKernelGGL(k_backup, dim3(count < 0 ? P.B : count), dim3(W), 0, st, Q, T, out, rec);
 }
 void launch_finish(hipStream_t st, const TreeParams& P, const TreeStore& T, const uint8_t* exploration_time,
                    const double* u, DeviceMoveOutputs o, unsigned long long* stats) {
