@@ -1,0 +1,166 @@
+"""DJL `.params` checkpoints <-> weight blob (muzero_amd/host/djl_params.{hpp,cpp}).
+
+PARITY UNPINNED: the reference ships no .params file and DJL is not importable here, so nothing can be checked
+against bytes DJL itself wrote.  What is checked: (1) the writer's bytes, parsed here independently with `struct`
+along the layout restated from DJL's sources (djl_params.hpp), say what that layout says; (2) write -> read returns
+the blob bit for bit, through the checkpoint's own tensor order (Representation, Prediction, Dynamics - the block
+insertion order of Network.java:96-100 - while the blob holds Representation, Dynamics, Prediction); (3) the reader
+copes with what a file written by DJL would add: block metadata bytes between the records, big-endian payloads,
+the projector / predictor arrays behind the inference nets, a LayerNorm pair stored beta-first; (4) a checkpoint of
+another network shape is refused."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from muzero_amd import netspec
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOOL = os.path.join(ROOT, "muzero_amd", "host", "bin", "djl_params_tool")
+
+
+def _tool(*args, ok=True):
+    r = subprocess.run([TOOL, *map(str, args)], capture_output=True, text=True)
+    assert (r.returncode == 0) == ok, r.stderr
+    return r.stdout.strip() if ok else r.stderr
+
+
+class _R:
+    def __init__(self, b):
+        self.b, self.p = b, 0
+
+    def take(self, fmt):
+        v = struct.unpack_from(">" + fmt, self.b, self.p)
+        self.p += struct.calcsize(">" + fmt)
+        return v[0] if len(v) == 1 else v
+
+    def utf(self):
+        n = self.take("H")
+        s = self.b[self.p:self.p + n].decode()
+        self.p += n
+        return s
+
+    def shape(self):
+        rank = self.take("i")
+        dims = [self.take("q") for _ in range(rank)]
+        for _ in range(self.take("i")):
+            self.take("H")
+        return dims
+
+
+def _utf(s):
+    return struct.pack(">H", len(s)) + s.encode()
+
+
+def _shape(dims):
+    return struct.pack(">i", len(dims)) + b"".join(struct.pack(">q", d) for d in dims) + struct.pack(">i", 0)
+
+
+def _record(name, arr, big_endian=False):
+    data = arr.astype(">f4" if big_endian else "<f4").tobytes()
+    return (struct.pack(">HB", ord("P"), 1) + _utf(name) + _utf("NDAR") + struct.pack(">iB", 3, 0) + _utf("DENSE") +
+            _utf("FLOAT32") + _shape(list(arr.shape)) + (b">" if big_endian else b"<") + struct.pack(">i", len(data)) + data)
+
+
+@pytest.mark.parametrize("game", ["tictactoe", "go9", "pegsolitair"])
+def test_write_read_round_trip_and_layout(game, tmp_path):
+    spec = netspec.SPECS[game]()
+    blob = netspec.pack_blob(spec, netspec.random_weights(spec, seed=5, ln_jitter=0.2))
+    src = tmp_path / "blob.bin"
+    blob.tofile(src)
+    path = _tool("write", game, src, tmp_path, "MuZero-" + game, 37)
+    assert os.path.basename(path) == f"MuZero-{game}-0037.params"      # BaseModel.save: "%s-%04d.params"
+    raw = open(path, "rb").read()
+
+    r = _R(raw)                                                          # independent parse of the documented layout
+    assert raw[:4] == b"DJL@"
+    r.p = 4
+    assert r.take("i") == 1 and r.utf() == "MuZero-" + game and r.utf() == "FLOAT32"
+    assert r.take("i") == 1 and r.utf() == "" and r.shape() == [1, spec.obs_planes, spec.height, spec.width]
+    props = {}
+    for _ in range(r.take("i")):
+        k = r.utf()
+        props[k] = r.utf()
+    assert props == {"Epoch": "37"}                                      # MySaveModelTrainingListener.java:139
+    assert r.take("B") == 1                                              # root block version
+    assert r.take("H") == ord("P") and r.take("B") == 1 and r.utf() == "weight"
+    assert r.utf() == "NDAR" and r.take("i") == 3 and r.take("B") == 0 and r.utf() == "DENSE" and r.utf() == "FLOAT32"
+    assert r.shape() == [spec.channels, spec.obs_planes, 3, 3]
+    assert r.take("B") == ord("<")
+    n = r.take("i")
+    first = np.frombuffer(raw, "<f4", n // 4, r.p)
+    np.testing.assert_array_equal(first, blob[:n // 4])                  # rep.conv0 leads both orders
+
+    out = tmp_path / "back.bin"
+    info = _tool("read", game, path, out).split()
+    assert info[0] == "MuZero-" + game and info[1] == "37" and int(info[2]) == len(netspec.tensor_list(spec)) and info[3] == "2"
+    assert np.fromfile(out, np.float32).tobytes() == blob.tobytes()
+
+
+def test_reader_takes_what_a_djl_written_file_would_add(tmp_path):
+    game = "go5"
+    spec = netspec.SPECS[game]()
+    w = netspec.random_weights(spec, seed=9, ln_jitter=0.3)
+    blob = netspec.pack_blob(spec, w)
+    order = [ln.split()[0] for ln in _tool("list", game).splitlines()]
+    names = [n for n, _ in netspec.tensor_list(spec)]
+    assert sorted(order) == sorted(names)
+    first_pred, first_dyn = order.index("pred.p.conv"), order.index("dyn.conv0")
+    assert order[0] == "rep.conv0" and first_pred < first_dyn            # Representation, Prediction, Dynamics
+    shapes = dict(netspec.tensor_list(spec))
+    body = b"\x03" + struct.pack(">i", 1) + _shape([1, 17, 5, 5])        # a block version byte + input-shape metadata
+    i = 0
+    swapped = False
+    while i < len(order):
+        n = order[i]
+        leaf = n.split(".")[-1]
+        if leaf == "g" and not swapped and n.startswith("dyn.b3"):       # one LayerNorm pair stored beta first
+            body += _record("beta", w[order[i + 1]]) + _record("gamma", w[n])
+            swapped = True
+            i += 2
+            continue
+        pname = "gamma" if leaf == "g" else "beta" if (leaf == "b" and ".ln" in n) else \
+            "bias" if leaf in ("b", "bb") else "weight"
+        arr = w[n]
+        if len(shapes[n]) == 2 and ".ln" in n:
+            arr = arr.reshape(shapes[n][0], spec.height, spec.width)     # DJL's LayerNorm shape [C, H, W]
+        body += _record(pname, arr, big_endian=(i % 3 == 0))
+        body += b"\x02" + struct.pack(">i", 0)                           # more block metadata between the records
+        i += 1
+    assert swapped
+    rng = np.random.default_rng(0)                                       # "04Projector" / "05Predictor" arrays follow
+    body += _record("weight", rng.standard_normal((64, 32)).astype(np.float32)) + _record("bias", np.zeros(64, np.float32))
+    head = b"DJL@" + struct.pack(">i", 1) + _utf("MuZero-Go5") + _utf("FLOAT32") + struct.pack(">i", 0) + \
+        struct.pack(">i", 2) + _utf("Epoch") + _utf("120") + _utf("MeanLoss") + _utf("0.5")
+    path = tmp_path / "MuZero-Go5-0120.params"
+    path.write_bytes(head + body)
+    out = tmp_path / "blob.bin"
+    info = _tool("read", game, path, out).split()
+    assert info[:2] == ["MuZero-Go5", "120"] and int(info[2]) == len(names) + 2
+    assert np.fromfile(out, np.float32).tobytes() == blob.tobytes()
+
+
+def test_other_network_shape_is_refused(tmp_path):
+    spec = netspec.spec_tictactoe()
+    blob = netspec.pack_blob(spec, netspec.random_weights(spec, seed=1))
+    src = tmp_path / "blob.bin"
+    blob.tofile(src)
+    path = _tool("write", "tictactoe", src, tmp_path, "m", 1)
+    assert "parameter arrays" in _tool("read", "go9", path, tmp_path / "x.bin", ok=False)        # fewer blocks
+    # same number of blocks, other board: Go 5x5 weights offered as Go 9x9... no; TicTacToe (R = 6) vs itself with
+    # one array cut short is caught by the element count
+    raw = bytearray(open(path, "rb").read())
+    at = raw.find(b"\x00\x04NDAR", raw.find(b"\x00\x04NDAR") + 1)          # second record: rep.b0.ln1 gamma [256,3,3]
+    dim0 = raw.find(struct.pack(">q", 256), at)
+    raw[dim0:dim0 + 8] = struct.pack(">q", 255)
+    cut = tmp_path / "cut.params"
+    cut.write_bytes(bytes(raw))
+    assert "byte length does not match" in _tool("read", "tictactoe", cut, tmp_path / "x.bin", ok=False)
+    bad = tmp_path / "bad.params"
+    bad.write_bytes(b"XXXX" + open(path, "rb").read()[4:])
+    assert "DJL@" in _tool("read", "tictactoe", bad, tmp_path / "x.bin", ok=False)
+    src2 = tmp_path / "short.bin"
+    blob[:-3].tofile(src2)
+    assert "floats" in _tool("write", "tictactoe", src2, tmp_path, "m", 1, ok=False)
