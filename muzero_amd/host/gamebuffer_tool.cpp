@@ -1,11 +1,17 @@
 // gamebuffer_tool - writes a replay buffer in the reference's format from episodes played by the host mirror
 // (fastRulesLearning: no GPU needed) and checks the round trip.  Used by tests/test_game_buffer_proto.py, which decodes
 // the bytes with an independent protobuf implementation built from the reference's GameBuffer.proto schema.
-// usage: gamebuffer_tool <outdir> <numGames> <seed>
+// usage: gamebuffer_tool <outdir> <numGames> <seed> [<weights.f32> <gpu|initial>]
 //   writes <outdir>/buffer.dat (GameBufferProto bytes), <outdir>/<network>-protobuf.zip, <outdir>/buffer.json
+//   with a weight blob the episodes are played ON THE DEVICE through the C ABI - "gpu": the Gumbel search
+//   (mz_search_moves per move), "initial": PlanAction.playAfterJustWithInitialInference - and buffer.json also carries,
+//   per game, the trace of what every planActions call got from the device (MoveRecord), so that a test can follow
+//   every number from mz_move_outputs into the replay-buffer bytes.
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
+#include <iterator>
+#include <memory>
 
 #include "game_buffer_proto.hpp"
 
@@ -23,11 +29,28 @@ int main(int argc, char** argv) {
         const std::string outdir = argv[1];
         const int n = std::atoi(argv[2]);
         MuZeroConfig config = MuZeroConfig::tictactoe();
-        ModelService noDevice(config);
-        PlayService playService(noDevice, std::strtoull(argv[3], nullptr, 10));
+        const std::string mode = argc > 5 ? argv[5] : "fastrules";
+        std::unique_ptr<ModelService> service;
+        if (mode == "fastrules") {
+            service.reset(new ModelService(config));
+        } else {
+            config.setPlayTypeKey(PlayTypeKey::HYBRID);   // Gumbel + Dirichlet noise, temperature sampling: every output in use
+            config.hybridTraining = true;
+            std::ifstream wf(argv[4], std::ios::binary);
+            std::vector<char> raw((std::istreambuf_iterator<char>(wf)), std::istreambuf_iterator<char>());
+            if (raw.empty()) throw MuZeroException("cannot read the weight blob");
+            service.reset(new ModelService(config, n, MZ_PRECISION_F16, 0, mode == "initial" ? n : 0));
+            service->loadWeights(reinterpret_cast<const float*>(raw.data()), raw.size() / sizeof(float));
+        }
+        PlayService playService(*service, std::strtoull(argv[3], nullptr, 10));
+        playService.maxGameLength = 9;
+        std::vector<MoveRecord> trace;
+        playService.setTrace(&trace);
         PlayParameters p;
         p.render = false;
-        p.fastRulesLearning = true;
+        p.fastRulesLearning = mode == "fastrules";
+        p.justInitialInferencePolicy = mode == "initial";
+        p.withGumbel = mode == "gpu";
         auto games = playService.playNewGames(n, p);
 
         GameBufferDTO buffer;
@@ -76,7 +99,41 @@ int main(int argc, char** argv) {
             jsonFloats(f, "root_value_targets", d.rootValueTargets);
             std::fprintf(f, ", ");
             jsonFloats(f, "max_entropies", d.legalActionMaxEntropies);
-            std::fprintf(f, ", \"policy_targets\": [");
+            std::fprintf(f, ", ");
+            jsonFloats(f, "v_mix", d.vMix);
+            std::fprintf(f, ", ");
+            jsonFloats(f, "entropies", d.entropies);
+            std::fprintf(f, ", ");
+            jsonFloats(f, "root_values_from_initial_inference", d.rootValuesFromInitialInference);
+            std::fprintf(f, ", ");
+            jsonFloats(f, "root_entropy_value_targets", d.rootEntropyValueTargets);
+            std::fprintf(f, ", \"playout_policy\": [");
+            for (size_t t = 0; t < d.playoutPolicy.size(); t++) {
+                std::fprintf(f, "%s[", t ? ", " : "");
+                for (size_t i = 0; i < d.playoutPolicy[t].size(); i++) std::fprintf(f, "%s%.9g", i ? ", " : "", d.playoutPolicy[t][i]);
+                std::fprintf(f, "]");
+            }
+            std::fprintf(f, "], \"trace\": [");
+            bool firstRec = true;
+            for (const MoveRecord& r : trace) {
+                if (r.game != games[g].get()) continue;
+                std::fprintf(f, "%s{\"move\": %d, \"action\": %d, \"simulations\": %d, \"playout_appended\": %d, \"just_initial\": %d, "
+                                "\"root_value_target\": %.9g, \"v_mix\": %.9g, \"root_value_inference\": %.9g, \"entropy\": %.9g, "
+                                "\"max_entropy\": %.9g, \"root_entropy_value_target\": %.9g, \"u\": %.17g, ",
+                             firstRec ? "" : ", ", r.moveIndex, r.action, r.simulations, r.playoutAppended ? 1 : 0,
+                             r.justInitialInference ? 1 : 0, r.rootValueTarget, r.vMix, r.rootValueInference, r.entropy, r.maxEntropy,
+                             r.rootEntropyValueTarget, r.u);
+                jsonFloats(f, "policy_target", r.policyTarget);
+                std::fprintf(f, ", ");
+                jsonFloats(f, "playout_policy", r.playoutPolicy);
+                std::fprintf(f, ", ");
+                jsonFloats(f, "network_policy", r.networkPolicy);
+                std::fprintf(f, ", \"legal\": [");
+                for (size_t i = 0; i < r.legal.size(); i++) std::fprintf(f, "%s%d", i ? ", " : "", r.legal[i]);
+                std::fprintf(f, "]}");
+                firstRec = false;
+            }
+            std::fprintf(f, "], \"policy_targets\": [");
             for (size_t t = 0; t < d.policyTargets.size(); t++) {
                 std::fprintf(f, "%s[", t ? ", " : "");
                 for (size_t i = 0; i < d.policyTargets[t].size(); i++) std::fprintf(f, "%s%.9g", i ? ", " : "", d.policyTargets[t][i]);

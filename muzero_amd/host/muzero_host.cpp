@@ -599,6 +599,23 @@ std::vector<Action> PlanAction::planActions(const std::vector<Game*>& games, con
         dto.policyTargets.emplace_back(policyTarget.begin() + o, policyTarget.begin() + o + A);
         if (sims[g] > 0) dto.rootEntropyValueTargets.push_back(rootEntropyValueTarget[g]);   // GumbelSearch.java:75-114 only
         simulationsRun += sims[g];
+        if (trace) {
+            MoveRecord r;
+            r.game = games[g];
+            r.moveIndex = static_cast<int>(dto.actions.size());
+            r.action = action[g];
+            r.simulations = sims[g];
+            r.playoutAppended = playoutAppended[g] != 0;
+            r.rootValueTarget = rootValueTarget[g];
+            r.vMix = vMix[g];
+            r.rootValueInference = rootValueInference[g];
+            r.entropy = entropy[g];
+            r.maxEntropy = maxEntropy[g];
+            r.rootEntropyValueTarget = rootEntropyValueTarget[g];
+            r.policyTarget.assign(policyTarget.begin() + o, policyTarget.begin() + o + A);
+            r.playoutPolicy.assign(playout.begin() + o, playout.begin() + o + A);
+            trace->push_back(std::move(r));
+        }
         if (p.replay) {
             // GumbelSearch.selectAction :365-370 / PlanAction.java:161-163: the search ran, but the move is the original
             // game's and no playout policy is recorded
@@ -708,6 +725,21 @@ std::vector<Action> PlanAction::planActionsJustInitialInference(const std::vecto
         dto.vMix.push_back(0.f);
         dto.rootEntropyValueTargets.push_back(0.f);
         dto.policyTargets.push_back(policyTarget);
+        if (trace) {
+            MoveRecord r;
+            r.game = games[g];
+            r.moveIndex = static_cast<int>(dto.actions.size());
+            r.action = pick;
+            r.justInitialInference = true;
+            r.entropy = static_cast<float>(ent);
+            r.maxEntropy = dto.legalActionMaxEntropies.back();
+            r.policyTarget = policyTarget;
+            r.networkPolicy = io[g].policyValues;
+            r.legal.assign(A, 0);
+            for (const Action& a : la) r.legal[a.getIndex()] = 1;
+            r.u = u;
+            trace->push_back(std::move(r));
+        }
         result.push_back(config.newAction(pick));
     }
     return result;

@@ -293,6 +293,21 @@ struct PlayParameters {
 };
 
 // P/agent/c_planning/PlanAction.java:68-171, batched: one planned move for every game of `games`.
+// What one planActions call handed to / got from the device for one game (tests compare it with the oracle and with
+// what lands in the replay buffer): the raw mz_move_outputs of the move, or - justInitialInferencePolicy - the network
+// policy, the legal actions and the uniform draw the move was made from.
+struct MoveRecord {
+    const Game* game = nullptr;
+    int moveIndex = 0;              // position of the move in the episode
+    int action = -1, simulations = 0;
+    bool playoutAppended = false, justInitialInference = false;
+    float rootValueTarget = 0, vMix = 0, rootValueInference = 0, entropy = 0, maxEntropy = 0, rootEntropyValueTarget = 0;
+    std::vector<float> policyTarget, playoutPolicy;
+    std::vector<float> networkPolicy;   // justInitialInference: NetworkIO.policyValues
+    std::vector<uint8_t> legal;         // justInitialInference
+    double u = 0;                       // justInitialInference: the draw of selectActionByDrawingFromDistribution
+};
+
 class PlanAction {
 public:
     PlanAction(ModelService& modelService, uint64_t seed) : modelService(modelService), rng(seed) {}
@@ -304,6 +319,7 @@ public:
     // PlanAction.java:34-65, batched
     void justReplayActionsWithInitialInference(const std::vector<Game*>& games);
     int64_t simulationsRun = 0;
+    std::vector<MoveRecord>* trace = nullptr;   // when set: one record per game and planActions call
 
 private:
     std::vector<Action> planActionsFastRules(const std::vector<Game*>& games, const PlayParameters& p);
@@ -323,6 +339,7 @@ public:
     void hybridConfiguration(const std::vector<Game*>& games, int gameLength);         // :92-103
     int maxGameLength = 0;  // gameBuffer.getMaxGameLength()
     int64_t simulationsRun() const { return planAction.simulationsRun; }
+    void setTrace(std::vector<MoveRecord>* t) { planAction.trace = t; }
 
 private:
     ModelService& modelService;

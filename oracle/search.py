@@ -66,6 +66,7 @@ def lib():
         _lib.mzo_java_sum.restype = C.c_double
         _lib.mzo_entropy.argtypes = [C.c_void_p, C.c_int]
         _lib.mzo_entropy.restype = C.c_double
+        _lib.mzo_fast_rule_learning_move.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     return _lib
 
 
@@ -266,3 +267,31 @@ def java_sum(v):
 def entropy(p):
     p = np.ascontiguousarray(p, np.float32)
     return lib().mzo_entropy(_p(p), len(p))
+
+
+def play_after_just_initial_inference(legal, policy, logits, u):
+    """PlanAction.playAfterJustWithInitialInference -> (action, policy_target float32[A])."""
+    legal = np.ascontiguousarray(legal, np.uint8)
+    policy = np.ascontiguousarray(policy, np.float32)
+    logits = np.ascontiguousarray(logits, np.float32)
+    A = legal.size
+    pt = np.zeros(A, np.float32)
+    rvt, vmix = C.c_float(), C.c_float()
+    L = lib()
+    L.mzo_play_after_just_initial_inference.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double,
+                                                        C.c_void_p, C.c_void_p, C.c_void_p]
+    a = L.mzo_play_after_just_initial_inference(_p(legal), _p(policy), _p(logits), A, float(u), _p(pt), C.byref(rvt),
+                                                C.byref(vmix))
+    if a < 0:
+        raise ValueError("no legal action")
+    return a, pt
+
+
+def fast_rule_learning_move(legal, r):
+    """fastRuleLearning root -> (action, policy_target float32[A]); r = the nextInt(0, L - 1) draw."""
+    legal = np.ascontiguousarray(legal, np.uint8)
+    pt = np.zeros(legal.size, np.float32)
+    a = lib().mzo_fast_rule_learning_move(_p(legal), legal.size, int(r), _p(pt))
+    if a < 0:
+        raise ValueError("bad draw or no legal action")
+    return a, pt

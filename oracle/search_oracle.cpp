@@ -921,4 +921,76 @@ double mzo_java_sum(const double* v, int n) {
 }
 double mzo_entropy(const float* p, int n) { return entropy_of(p, n); }
 
+// PlanAction.playAfterJustWithInitialInference (PlanAction.java:174-193), the justInitialInferencePolicy branch of
+// planAction (:85-87): the root is expanded from the initial inference (Node.expandRootNode -> renormPrior,
+// Node.java:272-307,252-269: HashMap child order, Kahan DoubleStream.sum), the move is drawn from (action, prior) in child
+// order (Functions.selectActionByDrawingFromDistribution, Functions.java:118-126) and the priors are the policy target
+// (GumbelSearch.storeSearchStatistics with justPriorValues, GumbelSearch.java:75-88: a fresh root has improvedValue =
+// vmix = improvedEntropyValue = 0).  The draw is commons-math3 3.6.1 EnumeratedDistribution (third party, not under
+// /root/reference; restated from its published source): weights normalised by their plain left-to-right sum
+// (MathArrays.normalizeArray: w * 1.0 / sum), cumulative sums in list order, sample() = binary search of the uniform
+// draw in the cumulative array; an exact hit on a cumulative value or a draw beyond the last one returns the LAST item.
+// u = that uniform draw (an input, like all noise here).  Returns the action index; policy_target[A] gets (float) prior.
+int mzo_play_after_just_initial_inference(const uint8_t* legal, const float* policy, const float* logits, int A, double u,
+                                          float* policy_target, float* root_value_target, float* v_mix) {
+    std::vector<int> legalActions, order;
+    for (int a = 0; a < A; a++)
+        if (legal[a]) legalActions.push_back(a);
+    if (legalActions.empty() || !java_hashmap_order(legalActions, order)) return -1;
+    JavaSum s;
+    for (int a : order) s.add((double)policy[a]);
+    const double policySum = s.result();
+    std::vector<double> prior;
+    for (int a : order) prior.push_back(policy[a] / policySum);
+    (void)logits;   // kept by the children (Node.java:262) but never read on this branch
+    for (int a = 0; a < A; a++) policy_target[a] = 0.f;
+    for (size_t i = 0; i < order.size(); i++) policy_target[order[i]] = (float)prior[i];
+    *root_value_target = 0.f;
+    *v_mix = 0.f;
+    // EnumeratedDistribution(rng, pmf)
+    double sum = 0.0;
+    for (double w : prior) sum += w;
+    std::vector<double> cum(prior.size());
+    double c = 0.0;
+    for (size_t i = 0; i < prior.size(); i++) {
+        c += prior[i] * 1.0 / sum;
+        cum[i] = c;
+    }
+    // sample(): Arrays.binarySearch(cumulativeProbabilities, u)
+    int lo = 0, hi = (int)cum.size() - 1, index = -1;
+    while (lo <= hi) {
+        const int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1);
+        if (cum[mid] < u) lo = mid + 1;
+        else if (cum[mid] > u) hi = mid - 1;
+        else {
+            index = mid;
+            break;
+        }
+    }
+    if (index < 0) index = lo;   // -(insertion point) - 1 -> insertion point
+    if (index >= 0 && index < (int)cum.size() && u < cum[index]) return order[index];
+    return order.back();
+}
+
+// fastRuleLearning root (Node.expandRootNode, Node.java:289-294; planAction :81-84,104-110,134-141;
+// storeSearchStatistics with justPriorValues; GumbelSearch.selectAction :372-378): no network, every legal action gets
+// the prior 1.0 / |legal| (children in the order of game.legalActions(), ascending index), the policy target is that
+// prior and the move is root.getRandomAction() = children[nextInt(0, size - 1)] (Node.java:188-191: the bound is
+// exclusive, so the last child is never drawn).  r = that integer draw.  Returns the action index.
+int mzo_fast_rule_learning_move(const uint8_t* legal, int A, int r, float* policy_target) {
+    std::vector<int> legalActions;
+    for (int a = 0; a < A; a++)
+        if (legal[a]) legalActions.push_back(a);
+    if (legalActions.empty()) return -1;
+    for (int a = 0; a < A; a++) policy_target[a] = 0.f;
+    if (legalActions.size() == 1) {   // shortCutForGameWithoutAnOption, PlanAction.java:147-171
+        policy_target[legalActions[0]] = 1.f;
+        return legalActions[0];
+    }
+    const double p = 1.0 / (double)legalActions.size();
+    for (int a : legalActions) policy_target[a] = (float)p;
+    if (r < 0 || r >= (int)legalActions.size() - 1) return -1;
+    return legalActions[r];
+}
+
 }  // extern "C"
