@@ -69,7 +69,7 @@ void run(const char* name, float* out, unsigned long long* cyc, int grid) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_loop<LOOK, BAR, NROW, NC, PRIO>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
-    for (int rep = 0; rep < 2; rep++) {
+    for (int rep = 0; rep < 6; rep++) {   // the clock settles over the first launches (DVFS): the last one is reported
         hipEventRecord(a);
         hipLaunchKernelGGL((k_loop<LOOK, BAR, NROW, NC, PRIO>), dim3(grid), dim3(512), lds, 0, out, cyc, iters);
         hipEventRecord(b);
@@ -82,8 +82,8 @@ void run(const char* name, float* out, unsigned long long* cyc, int grid) {
     for (int g = 0; g < grid; g++) { mx0 += c[g * 8 + 0]; mx4 += c[g * 8 + 7]; }
     const double mf = (double)iters * KK * NROW * NC;   // MFMAs per wave
     const double flops = (double)grid * 8 * mf * 32768.0;
-    printf("%-28s %7.3f ms  %7.1f TFLOP/s  cycles/MFMA/SIMD: wave0 %.1f wave7 %.1f  (clock %.2f GHz)\n", name, ms, flops / ms / 1e9,
-           mx0 / grid / mf / 2, mx4 / grid / mf / 2, mx4 / grid / (ms * 1e6));
+    printf("%-28s %7.3f ms  %7.1f TFLOP/s  cycles/MFMA/SIMD: wave0 %.1f wave7 %.1f  (shader clock %.2f GHz)\n", name, ms, flops / ms / 1e9,
+           mx0 / grid / mf / 2, mx4 / grid / mf / 2, mx4 / grid * (grid / 256.0) / (ms * 1e6));
 }
 
 int main() {

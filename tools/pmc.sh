@@ -1,11 +1,12 @@
 #!/bin/bash
 # PMC passes for the inference kernels (each pass its own run, within the per-block counter limits).
-# Usage (on the GPU box): bash tools/pmc.sh <tag> [games] [workload]
+# Usage (on the GPU box): bash tools/pmc.sh <tag> [games] [workload] [precision]
 #   -> gpurun_out/pmc_<tag>/summary.txt and traffic_<workload>_<games>.json (copy both into profiles/)
 set -e
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$1
 GAMES=${2:-4096}
 WL=${3:-go9}
+PREC=${4:-f16}
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS"
@@ -16,18 +17,18 @@ P5="GRBM_GUI_ACTIVE"
 i=0
 for P in "$P1" "$P2" "$P3" "$P4" "$P5"; do
   i=$((i+1))
-  timeout -s KILL 120 rocprofv3 --pmc $P --output-format csv -d $OUT/p$i -- python3 $GRAFT_REPO_ROOT/tools/bench_net.py --workload $WL --games $GAMES --iters 3 > $OUT/p$i.log 2>&1
+  timeout -s KILL 120 rocprofv3 --pmc $P --output-format csv -d $OUT/p$i -- python3 $GRAFT_REPO_ROOT/tools/bench_net.py --workload $WL --games $GAMES --iters 3 --precision $PREC > $OUT/p$i.log 2>&1
 done
 python3 - <<PY > $OUT/summary.txt
 import csv, glob, collections, json, re
-print("# per-dispatch averages over the recurrentInference launches of tools/bench_net.py --workload $WL --games $GAMES (rocprofv3 --pmc, one pass per counter group)")
+print("# per-dispatch averages over the recurrentInference launches of tools/bench_net.py --workload $WL --games $GAMES --precision $PREC (rocprofv3 --pmc, one pass per counter group)")
 traffic = {"fetch": {}, "write": {}}
 for i in (1, 2, 3, 4, 5):
     fs = glob.glob("$OUT/p%d/**/*counter_collection.csv" % i, recursive=True)
     agg = collections.defaultdict(lambda: collections.defaultdict(float)); disp = collections.defaultdict(set)
     for f in fs:
         for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].replace("mz::(anonymous namespace)::", "").replace("void ", "")[:44]
+            k = re.sub(r"mz::(\(anonymous namespace\)|impl_f16|impl_bf16)::", "", r["Kernel_Name"]).replace("void ", "")[:44]
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
             disp[k].add(r["Dispatch_Id"])
     for k, v in sorted(agg.items()):
@@ -42,8 +43,8 @@ for i in (1, 2, 3, 4, 5):
 # HBM bytes per recurrentInference launch chain.  gfx950: FETCH_SIZE (KB) tallies 128-B requests at 64 B for wide
 # coalesced reads -> doubled; WRITE_SIZE (KB) is exact (MI355X_MICROARCH.md, HBM).
 fetch_kb = sum(traffic["fetch"].values()); write_kb = sum(traffic["write"].values())
-json.dump({"source": "tools/pmc.sh $1 $GAMES $WL: tools/bench_net.py, FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc passes",
-           "workload": "$WL", "precision": "bf16", "games": $GAMES,
+json.dump({"source": "tools/pmc.sh $1 $GAMES $WL $PREC: tools/bench_net.py, FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc passes",
+           "workload": "$WL", "precision": "$PREC", "games": $GAMES,
            "fetch_size_kb_per_launch": traffic["fetch"], "write_size_kb_per_launch": traffic["write"],
            "note": "gfx950: FETCH_SIZE tallies 128-B requests at 64 B -> doubled; WRITE_SIZE exact",
            "bytes_per_sample": (2 * fetch_kb + write_kb) * 1024.0 / $GAMES},
