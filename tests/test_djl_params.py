@@ -149,8 +149,7 @@ def test_other_network_shape_is_refused(tmp_path):
     blob.tofile(src)
     path = _tool("write", "tictactoe", src, tmp_path, "m", 1)
     assert "parameter arrays" in _tool("read", "go9", path, tmp_path / "x.bin", ok=False)        # fewer blocks
-    # same number of blocks, other board: Go 5x5 weights offered as Go 9x9... no; TicTacToe (R = 6) vs itself with
-    # one array cut short is caught by the element count
+    # same arrays, one dimension off by one: the record's byte length no longer matches its shape
     raw = bytearray(open(path, "rb").read())
     at = raw.find(b"\x00\x04NDAR", raw.find(b"\x00\x04NDAR") + 1)          # second record: rep.b0.ln1 gamma [256,3,3]
     dim0 = raw.find(struct.pack(">q", 256), at)
