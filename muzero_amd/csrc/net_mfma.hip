@@ -105,14 +105,15 @@ constexpr int ZROWS = 16;
 
 #if defined(MZ_STAMPS)  // diagnostic build: per-phase cycle counts of workgroup 0 (waves 0 and 7), printed by the kernel
 #define STAMP(c, i) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); (c).st_acc[i] += (unsigned)(t_ - (c).st_last); (c).st_last = t_; } while (0)
-#define STAMP_PRINT(c, name) do { if (blockIdx.x == 0 && ((c).wave == 0 || (c).wave == 4 || (c).wave == 7) && (c).lane == 0) \
-    printf("%s w%d: stats %u norm %u acquire %u mma %u xload %u xstore %u rescale %u head %u other %u bcast %u | hconv %u hln %u hfc %u\n", name, (c).wave, \
-           (c).st_acc[0], (c).st_acc[1], (c).st_acc[2], (c).st_acc[3], (c).st_acc[4], (c).st_acc[5], (c).st_acc[6], (c).st_acc[7], (c).st_acc[8], (c).st_acc[9], (c).st_acc[10], (c).st_acc[11], (c).st_acc[12]); } while (0)
+#define STAMP_PRINT(c, name) do { if (blockIdx.x == 0 && ((c).wave == 0 || (c).wave == 2 || (c).wave == 4 || (c).wave == 7) && (c).lane == 0) \
+    printf("%s w%d: stats %u norm %u acquire %u mma %u xload %u xstore %u rescale %u head %u other %u bcast %u | hconv %u hln %u hfc %u | sbar %u scomb %u\n", name, (c).wave, \
+           (c).st_acc[0], (c).st_acc[1], (c).st_acc[2], (c).st_acc[3], (c).st_acc[4], (c).st_acc[5], (c).st_acc[6], (c).st_acc[7], (c).st_acc[8], (c).st_acc[9], (c).st_acc[10], (c).st_acc[11], (c).st_acc[12], (c).st_acc[13], (c).st_acc[14]); } while (0)
 #else
 #define STAMP(c, i)
 #define STAMP_PRINT(c, name)
 #endif
-enum { ST_STATS = 0, ST_NORM, ST_ACQ, ST_MMA, ST_XLOAD, ST_XSTORE, ST_RESCALE, ST_HEAD, ST_OTHER, ST_BCAST, ST_HCONV, ST_HLN, ST_HFC };
+enum { ST_STATS = 0, ST_NORM, ST_ACQ, ST_MMA, ST_XLOAD, ST_XSTORE, ST_RESCALE, ST_HEAD, ST_OTHER, ST_BCAST, ST_HCONV, ST_HLN, ST_HFC,
+       ST_SBAR, ST_SCOMB };
 
 enum { IN_OBS = 0, IN_HIDDEN = 1, IN_X = 2 };
 enum { OUT_X = 0, OUT_FINAL = 1, OUT_REGS = 2 };   // OUT_REGS: X stays in registers (a fused kernel goes on)
@@ -213,7 +214,7 @@ struct Ctx {
     int parity;
     int* meta;       // [4][MAXNB]: src slot, dst slot, live, action cell
 #if defined(MZ_STAMPS)
-    unsigned st_acc[14];
+    unsigned st_acc[16];
     unsigned long long st_last;
 #endif
 };
@@ -248,9 +249,9 @@ struct WRing {
         for (int i = 0; i < (SM + NW - 1) / NW; i++) {
             const int f = wave + NW * i;
             if (f < nf) {
-                const char* gp = gptr + (size_t)f * 1024 + lane16;
                 const unsigned m0v = dst + f * 1024;
-                asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp), "s"(m0v) : "memory");
+                const char* gp = gptr + (size_t)f * 1024;   // scalar base + the lane's 32-bit offset: no vector address arithmetic
+                asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, %2" ::"v"(lane16), "s"(m0v), "s"(gp) : "memory");
             }
         }
         gptr += (size_t)nf * 1024;
@@ -328,8 +329,10 @@ __device__ __forceinline__ void board_reduce(Ctx& c, const Col (&k)[NC], float (
     float* wp = c.wpart + c.parity * (MAXNB * NW * 2);
     c.parity ^= 1;
     if (c.lane < c.NB) *reinterpret_cast<f32x2*>(wp + (c.lane * NW + c.wave) * 2) = (f32x2){ma, mb};
+    STAMP(c, ST_STATS);
     if (VM) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     else lds_barrier();
+    STAMP(c, ST_SBAR);
 #pragma unroll
     for (int ct = 0; ct < NC; ct++) {
         const int bd = k[ct].board < MAXNB ? k[ct].board : 0;
@@ -405,9 +408,9 @@ __device__ __forceinline__ void gtab_issue(Ctx& c, const u32x4* table, int bytes
     const unsigned dst = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)gtab;
     const int npieces = (bytes + 1023) >> 10;
     for (int f = c.wave; f < npieces; f += NW) {
-        const char* gp = reinterpret_cast<const char*>(table) + (size_t)f * 1024 + c.lane * 16;
         const unsigned m0v = dst + f * 1024;
-        asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp), "s"(m0v) : "memory");
+        const char* gp = reinterpret_cast<const char*>(table) + (size_t)f * 1024;
+        asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, %2" ::"v"(c.lane * 16), "s"(m0v), "s"(gp) : "memory");
     }
 }
 
@@ -478,7 +481,7 @@ __device__ __forceinline__ void ln_to_image(Ctx& c, const Col (&k)[NC], const u3
     float mean[NC], rstd[NC];
     STAMP(c, ST_OTHER);
     ln_stats<NR, NW, NC, LDSG>(c, k, v, nch, mean, rstd);
-    STAMP(c, ST_STATS);
+    STAMP(c, ST_SCOMB);
 #pragma unroll
     for (int rt = (LDSG ? 0 : 2); rt < NR; rt++)
 #pragma unroll
@@ -587,7 +590,7 @@ __device__ __forceinline__ void ln_to_regs(Ctx& c, const Col (&k)[NC], const u32
     float mean[NC], rstd[NC];
     STAMP(c, ST_OTHER);
     ln_stats<NR, NW, NC, LDSG>(c, k, v, nch, mean, rstd);
-    STAMP(c, ST_STATS);
+    STAMP(c, ST_SCOMB);
 #pragma unroll
     for (int rt = (LDSG ? 0 : 2); rt < NR; rt++)
 #pragma unroll
@@ -787,7 +790,7 @@ __device__ __forceinline__ void ctx_init(Ctx& c, char* smem, const LdsPlan& L, c
     c.parity = 0;
     c.meta = reinterpret_cast<int*>(smem + L.meta_off);
 #if defined(MZ_STAMPS)
-    for (int i = 0; i < 14; i++) c.st_acc[i] = 0;
+    for (int i = 0; i < 16; i++) c.st_acc[i] = 0;
     c.st_last = __builtin_amdgcn_s_memtime();
 #endif
 }

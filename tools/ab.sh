@@ -1,9 +1,10 @@
 #!/bin/bash
-# A/B of two builds on the same box: tools/ab.sh <games> <libA> <libB> ... (interleaved, two rounds)
+# A/B of several builds on the same box: tools/ab.sh <games> <libA> <libB> ... (interleaved, ${ABR:-2} rounds; ABX = extra
+# arguments for tools/bench_net.py, ABI = iterations per run)
 g=$1; shift
-for round in 1 2; do
+for round in $(seq 1 ${ABR:-2}); do
   for lib in "$@"; do
     echo -n "$(basename $lib): "
-    MZ_LIB=$PWD/$lib timeout -k 10 120 python3 tools/bench_net.py --games $g --iters 20 $ABX || exit 1
+    MZ_LIB=$PWD/$lib timeout -k 10 120 python3 tools/bench_net.py --games $g --iters ${ABI:-20} $ABX || exit 1
   done
 done

@@ -17,15 +17,21 @@ def main():
     ap.add_argument("--games", type=int, default=4096)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--zero", action="store_true", help="all-zero weights and inputs: same instruction stream, least switching power")
     args = ap.parse_args()
     spec = netspec.SPECS[args.workload]()
     B = args.games
     prec = {"bf16": capi.PRECISION_BF16, "f16": capi.PRECISION_F16, "fp32": capi.PRECISION_FP32}[args.precision]
     ctx = capi.Context(capi.make_config(spec, 4, 2, 50, max_games=1, precision=prec, pool_slots=2 * B))
-    ctx.load_weights(netspec.pack_blob(spec, netspec.random_weights(spec, seed=1)))
+    blob = netspec.pack_blob(spec, netspec.random_weights(spec, seed=1))
+    if args.zero:
+        blob[:] = 0
+    ctx.load_weights(blob)
     ctx.set_action_cells(netspec.action_cells_board(spec))
     rng = np.random.default_rng(0)
     obs = (rng.uniform(size=(B, spec.obs_planes, spec.height, spec.width)) < 0.3).astype(np.float32)
+    if args.zero:
+        obs[:] = 0
     s0 = np.arange(B, dtype=np.int32)
     ctx.initial_inference(obs, s0)
     act = rng.integers(0, spec.action_space, B).astype(np.int32)
