@@ -87,6 +87,43 @@ def cpu_baseline(spec, weights, n, m, c_visit, bounds, games, seed, max_batch=10
     return sims / dt, sims, dt, torch.get_num_threads()
 
 
+def fp32_leg(spec, weights, n, m, c_visit, bounds, games, obs, device):
+    """The same search on the exact-fp32 network path (MZ_PRECISION_FP32: the reference's arithmetic, fp32 MFMA), one move of
+    `games` games after a warm-up move, every kernel on one stream and timed: an extra, separately labelled figure - never `value`."""
+    import torch
+    from muzero_amd import capi, netspec
+    ctx = capi.Context(capi.make_config(spec, n, m, c_visit, known_bounds=bounds, max_games=games,
+                                        precision=capi.PRECISION_FP32, gumbel_seed=7), device=device)
+    ctx.set_action_cells(netspec.action_cells_board(spec))
+    ctx.load_weights(netspec.pack_blob(spec, weights))
+    ctx.set_stream_split(False)
+    legal = torch.ones((games, spec.action_space), dtype=torch.uint8, device=obs.device)
+    o = obs[:games].contiguous()
+    A, dev = spec.action_space, obs.device
+    outs = dict(action=torch.zeros(games, dtype=torch.int32, device=dev),
+                visit_counts=torch.zeros((games, A), dtype=torch.int32, device=dev),
+                policy_target=torch.zeros((games, A), dtype=torch.float32, device=dev),
+                root_value_target=torch.zeros(games, dtype=torch.float32, device=dev),
+                sims_run=torch.zeros(games, dtype=torch.int32, device=dev),
+                status=torch.zeros(games, dtype=torch.int32, device=dev))
+    ctx.search_moves(games, o, legal, outputs=outs)
+    ctx.synchronize()
+    ctx.set_timing(True)
+    t0 = time.perf_counter()
+    ctx.search_moves(games, o, legal, outputs=outs)
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    assert int(outs["status"].abs().sum().item()) == 0
+    dt = time.perf_counter() - t0
+    sims, _ = ctx.last_stats()
+    ms, cnt = ctx.get_timing()["recurrent"]
+    ctx.close()
+    tf = netspec.flops_per_sample(spec)["recurrent"] * games / (ms / max(cnt, 1) / 1e3) / 1e12 if ms > 0 else 0.0
+    return {"simulations_per_s": sims / dt, "games": games, "moves": 1, "dtype": "fp32",
+            "recurrent_ms": ms / max(cnt, 1), "achieved_tflops": tf, "peak_tflops": PEAK_TFLOPS["fp32"],
+            "frac": tf / PEAK_TFLOPS["fp32"], "kernel": "k_net_fp32 (v_mfma_f32_16x16x4_f32 convs)"}
+
+
 def find_traffic(workload, precision, games):
     """HBM bytes per launch of the dominant kernel chain from the PMC passes of tools/pmc.sh (FETCH_SIZE and WRITE_SIZE
     in separate rocprofv3 --pmc runs, gfx950 correction applied there).  Picks the newest committed
@@ -126,6 +163,8 @@ def main():
                     help="network arithmetic: fp32 exact kernels, or MFMA with bf16 / fp16 operands and fp32 accumulation")
     ap.add_argument("--cpu-games", type=int, default=1024, help="games in the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fp32-games", type=int, default=4096,
+                    help="games of the extra exact-fp32 leg (the same search on MZ_PRECISION_FP32: v_mfma_f32_16x16x4_f32); 0 = skip")
     args = ap.parse_args()
 
     import torch
@@ -274,6 +313,8 @@ def main():
                              "peak_GBps": 8000.0},
             "kernel_ms": {k: round(v, 3) for k, v in kernel_ms.items()},
         }
+        if args.fp32_games > 0 and world == 1 and args.precision != "fp32":
+            line["fp32_path"] = fp32_leg(spec, weights, n, m, c_visit, bounds, min(args.fp32_games, B), obs, local_rank)
         if not args.no_cpu_baseline and world == 1:   # timed beside the GPU at N = 1 only
             w_cpu = weights if weights is not None else netspec.random_weights(spec, seed=1)
             v, sims, secs, threads = cpu_baseline(spec, w_cpu, n, m, c_visit, bounds, args.cpu_games, seed=1000)
