@@ -696,7 +696,7 @@ __device__ __forceinline__ void bottleneck(Ctx& c, const Col (&k)[G::NC], WRing<
     constexpr bool LG = G::WR == 1;
     char* gtab = c.smem + c.L.img_off + (G::COLS * RSB + 1023) / 1024 * 1024;
     const int gbytes = G::NRB * 8 * (int)e * 16;
-    auto cp2 = [&]() { gtab_issue<G::NW>(c, gb2, gbytes, gtab); };
+    auto cp2 = [&]() { if (LG) gtab_issue<G::NW>(c, gb2, gbytes, gtab); };
     auto cp3 = [&]() { if (LG) gtab_issue<G::NW>(c, gb3, gbytes, gtab); };
     auto cp4 = [&]() { if (LG) gtab_issue<G::NW>(c, gb4, gbytes, gtab); };
 
@@ -724,7 +724,7 @@ __device__ __forceinline__ void bottleneck(Ctx& c, const Col (&k)[G::NC], WRing<
     // LN4 -> c4 (1x1, CB -> C) accumulated into X
     if constexpr (G::WR == 1) {
         u32x4 bop[KSB][G::NC];
-        ln_to_regs<G::NRB, G::NW, G::NC, true>(c, k, gb4, a1, CB, bop, gtab);
+        ln_to_regs<G::NRB, G::NW, G::NC, LG>(c, k, gb4, a1, CB, bop, gtab);
         conv_regs<G, KSB, G::NRC>(c, ring, bop, X, nx0, nx1);
     } else {
         ln_to_image<G::NRBW, G::NW, G::NC>(c, k, gb4, a1, CB, RSB);
