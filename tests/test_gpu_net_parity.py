@@ -21,9 +21,11 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 
 TOL = {capi.PRECISION_FP32: dict(h=2e-4, l=2e-4, p=2e-4, v=2e-4),
-       capi.PRECISION_BF16: dict(h=3e-2, l=3e-2, p=2e-2, v=8e-2),
-       # fp16 operands: inside the reference's own cross-backend bar allClose(1e-2, 1e-2) on every output
-       capi.PRECISION_F16: dict(h=4e-3, l=5e-3, p=3e-3, v=1e-2)}
+       capi.PRECISION_BF16: dict(h=3e-2, l=4.5e-2, p=2e-2, v=8e-2),
+       # fp16 operands: inside the reference's own cross-backend bar allClose(1e-2, 1e-2) on every output.  Bars set from a
+       # sweep over 400 random networks / batches (tools/fuzz_net_stats.py, profiles/r2_fuzz.txt): worst |err| / (1 + |ref|)
+       # hidden 1.3e-3, logits 4.5e-3 (PegSolitair, 16 blocks: 8.2e-3), policy 6.3e-4, value / scale 4.8e-3
+       capi.PRECISION_F16: dict(h=4e-3, l=1e-2, p=3e-3, v=1e-2)}
 
 
 def _specs():
