@@ -343,8 +343,30 @@ size_t count_params(const NetDims& d) {
 
 inline int pad4(int x) { return (x + 3) & ~3; }
 
-// [Cout][Cin][taps] -> [Cin][taps][CoutPad]
-void pack_conv(std::vector<float>& dst, long long& off_out, const float* w, int Cout, int Cin, int taps) {
+// [Cout][Cin][taps] -> [Cin][taps][CoutPad] for the vector-ALU conv of net_fp32.hip, or - where that kernel takes the conv to
+// the matrix cores (fp32_conv_on_mfma: whole 16-row tiles of output channels, boards of <= 96 cells) - the A operands of
+// v_mfma_f32_16x16x4_f32 in 4 KiB units (tap, row tile of 16 output channels, 64 input channels): unit[s4][lane][e] =
+// w[16 mt + lane % 16][4 (16 c16 + 4 s4 + e) + lane / 16][tap], zero beyond Cin, so that a lane's operands of 16 k-steps are
+// four 16-byte loads and a wave's load is 1 KiB contiguous.
+void pack_conv(std::vector<float>& dst, long long& off_out, const float* w, int Cout, int Cin, int taps, int HW = 1 << 30) {
+    if (fp32_conv_on_mfma(Cout, pad4(Cout), HW)) {
+        while (dst.size() % 4) dst.push_back(0.f);
+        const int nmt = Cout / 16, nc16 = (Cin + 63) / 64;
+        off_out = (long long)dst.size();
+        dst.resize(dst.size() + (size_t)taps * nmt * nc16 * 1024, 0.f);
+        float* o = dst.data() + off_out;
+        for (int t = 0; t < taps; t++)
+            for (int mt = 0; mt < nmt; mt++)
+                for (int c16 = 0; c16 < nc16; c16++) {
+                    float* u = o + ((size_t)(t * nmt + mt) * nc16 + c16) * 1024;
+                    for (int s = 0; s < 16; s++)
+                        for (int lane = 0; lane < 64; lane++) {
+                            const int ci = 4 * (16 * c16 + s) + lane / 16, co = 16 * mt + lane % 16;
+                            if (ci < Cin) u[(s / 4) * 256 + lane * 4 + (s % 4)] = w[((size_t)co * Cin + ci) * taps + t];
+                        }
+                }
+        return;
+    }
     const int cp = pad4(Cout);
     off_out = (long long)dst.size();
     dst.resize(dst.size() + (size_t)Cin * taps * cp, 0.f);
@@ -373,7 +395,7 @@ void pack_tower_f32(const NetDims& d, BlobWalker& bw, std::vector<float>& dst, T
     const int C = d.C, Cb = d.Cb, HW = d.HW;
     t.cin0 = cin0;
     while (dst.size() % 4) dst.push_back(0.f);
-    pack_conv(dst, t.conv0, bw.take((size_t)C * cin0 * 9), C, cin0, 9);
+    pack_conv(dst, t.conv0, bw.take((size_t)C * cin0 * 9), C, cin0, 9, HW);
     for (int i = 0; i < d.R; i++) {
         BlockOff& b = t.blocks[i];
         std::memset(&b, 0, sizeof(b));
@@ -383,24 +405,24 @@ void pack_tower_f32(const NetDims& d, BlobWalker& bw, std::vector<float>& dst, T
             pack_copy(dst, b.ln1g, bw.take((size_t)C * HW), (size_t)C * HW);
             pack_copy(dst, b.ln1b, bw.take((size_t)C * HW), (size_t)C * HW);
             while (dst.size() % 4) dst.push_back(0.f);
-            pack_conv(dst, b.c1, bw.take((size_t)Cb * C), Cb, C, 1);
+            pack_conv(dst, b.c1, bw.take((size_t)Cb * C), Cb, C, 1, HW);
             pack_copy(dst, b.ln2g, bw.take((size_t)Cb * HW), (size_t)Cb * HW);
             pack_copy(dst, b.ln2b, bw.take((size_t)Cb * HW), (size_t)Cb * HW);
             while (dst.size() % 4) dst.push_back(0.f);
-            pack_conv(dst, b.c2, bw.take((size_t)Cb * Cb * 9), Cb, Cb, 9);
+            pack_conv(dst, b.c2, bw.take((size_t)Cb * Cb * 9), Cb, Cb, 9, HW);
             pack_copy(dst, b.ln3g, bw.take((size_t)Cb * HW), (size_t)Cb * HW);
             pack_copy(dst, b.ln3b, bw.take((size_t)Cb * HW), (size_t)Cb * HW);
             while (dst.size() % 4) dst.push_back(0.f);
-            pack_conv(dst, b.c3, bw.take((size_t)Cb * Cb * 9), Cb, Cb, 9);
+            pack_conv(dst, b.c3, bw.take((size_t)Cb * Cb * 9), Cb, Cb, 9, HW);
             pack_copy(dst, b.ln4g, bw.take((size_t)Cb * HW), (size_t)Cb * HW);
             pack_copy(dst, b.ln4b, bw.take((size_t)Cb * HW), (size_t)Cb * HW);
             while (dst.size() % 4) dst.push_back(0.f);
-            pack_conv(dst, b.c4, bw.take((size_t)C * Cb), C, Cb, 1);
+            pack_conv(dst, b.c4, bw.take((size_t)C * Cb), C, Cb, 1, HW);
         } else {
             pack_copy(dst, b.ln1g, bw.take((size_t)C * HW), (size_t)C * HW);
             pack_copy(dst, b.ln1b, bw.take((size_t)C * HW), (size_t)C * HW);
             while (dst.size() % 4) dst.push_back(0.f);
-            pack_conv(dst, b.c1, bw.take((size_t)C * C), C, C, 1);
+            pack_conv(dst, b.c1, bw.take((size_t)C * C), C, C, 1, HW);
             pack_copy(dst, b.ln2g, bw.take((size_t)C * HW), (size_t)C * HW);
             pack_copy(dst, b.ln2b, bw.take((size_t)C * HW), (size_t)C * HW);
             pack_transpose(dst, b.bw, bw.take((size_t)HW * HW), HW, HW);  // W[q][p] -> Wt[p][q]
@@ -408,7 +430,7 @@ void pack_tower_f32(const NetDims& d, BlobWalker& bw, std::vector<float>& dst, T
             pack_copy(dst, b.ln3g, bw.take((size_t)C * HW), (size_t)C * HW);
             pack_copy(dst, b.ln3b, bw.take((size_t)C * HW), (size_t)C * HW);
             while (dst.size() % 4) dst.push_back(0.f);
-            pack_conv(dst, b.c2, bw.take((size_t)C * C), C, C, 1);
+            pack_conv(dst, b.c2, bw.take((size_t)C * C), C, C, 1, HW);
         }
     }
 }

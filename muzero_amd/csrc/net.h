@@ -20,7 +20,7 @@ struct BlockOff {
     long long ln1g, ln1b, c1, ln2g, ln2b, c2, ln3g, ln3b, c3, ln4g, ln4b, c4, bw, bb;
 };
 struct TowerOff {
-    long long conv0;     // [Cin][9][CoutPad]
+    long long conv0;     // [Cin][9][CoutPad], or A-operand units (fp32_conv_on_mfma)
     int cin0;            // input channels of conv0 (O or C+a)
     BlockOff blocks[kMaxResiduals];
 };
@@ -57,6 +57,8 @@ struct NetIO {
 void lds_optin(const void* fn);
 hipError_t take_optin_error();
 
+// true: k_net_fp32 runs this conv on v_mfma_f32_16x16x4_f32 and expects its weights in A-operand units (api.cpp:pack_conv)
+__host__ __device__ inline bool fp32_conv_on_mfma(int Cout, int CoutPad, int HW) { return (Cout & 15) == 0 && CoutPad == Cout && HW <= 96; }
 size_t fp32_lds_bytes(const NetDims& d);
 hipError_t launch_net_fp32(hipStream_t st, bool initial, const NetDims& d, const NetProgramF32* prog_dev,
                            const float* wbuf, const NetIO& io);

@@ -220,7 +220,7 @@ __device__ __forceinline__ void conv_mfma(int in_off, int out_off, const float* 
     const int jl = lane & 15, kq = lane >> 4;
     const int nmt = Cout >> 4;
     const int KS = (Cin + 3) >> 2;              // k-steps per tap
-    const int cstride = taps * Cout;            // floats between input channels in Wt
+    const int nc16 = (Cin + 63) >> 6;           // 4 KiB weight units per (tap, row tile): api.cpp:pack_conv
     const int ngroups = nmt / MT;
     for (int it = wave; it < ngroups * nsplit; it += NW) {
         const int mt0 = (it % ngroups) * MT, nt0 = (it / ngroups) * NTW;
@@ -231,35 +231,28 @@ __device__ __forceinline__ void conv_mfma(int in_off, int out_off, const float* 
             for (int nt = 0; nt < NTW; nt++) acc[m][nt] = (f32x4v){0.f, 0.f, 0.f, 0.f};
         // (an explicit global pointer: in this out-of-line function Wt is a generic pointer, and a flat_load counts on
         // lgkmcnt as well, so every wait for a B operand would also wait for the A chunk requested ahead)
-        typedef const __attribute__((address_space(1))) float* gptr_t;
-        gptr_t wlane = (gptr_t)(Wt) + 16 * mt0 + jl;
+        typedef const __attribute__((address_space(1))) f32x4v* gptr_t;
+        gptr_t wlane = (gptr_t)(Wt) + lane;
+        // the chunk's A operands: CH / 4 sixteen-byte loads per row tile, each 1 KiB contiguous over the wave; channels beyond
+        // Cin are zeros in the packed units
         auto load_a = [&](int t, int s0, float (&a)[CH][MT]) {
 #pragma unroll
-            for (int s = 0; s < CH; s++) {
-                int ci = 4 * (s0 + s) + kq;
-                ci = ci < Cin ? ci : Cin - 1;
-                gptr_t w = wlane + (long long)ci * cstride + t * Cout;
+            for (int j = 0; j < CH / 4; j++) {
+                const int qd = (s0 >> 2) + j;
 #pragma unroll
-                for (int m = 0; m < MT; m++) a[s][m] = w[16 * m];
+                for (int m = 0; m < MT; m++) {
+                    const f32x4v v = wlane[(((t * nmt + mt0 + m) * nc16 + (qd >> 2)) * 4 + (qd & 3)) * 64];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) a[4 * j + e][m] = v[e];
+                }
             }
         };
-        auto mask_a = [&](int s0, float (&a)[CH][MT]) {   // after the loads have landed: zero the channels beyond Cin
-#pragma unroll
-            for (int s = 0; s < CH; s++) {
-#pragma unroll
-                for (int m = 0; m < MT; m++) asm volatile("" : "+v"(a[s][m]));
-                const bool ok = 4 * (s0 + s) + kq < Cin;
-#pragma unroll
-                for (int m = 0; m < MT; m++) a[s][m] = ok ? a[s][m] : 0.f;
-            }
-        };
-        const bool ragged = (Cin & 15) != 0;    // a group of four k-steps runs past Cin: only the convs that open a tower (O, C + a)
         float a0[CH][MT], a1[CH][MT];
         load_a(0, 0, a0);
-        if (ragged) mask_a(0, a0);
         int qoff[NTW], hwm[NTW];
         int t = 0, s0 = 0;
         // one chunk: request the next chunk's A operands into `an`, run this chunk's MFMAs from `a`; returns false after the last
+        // (a third set, two chunks in flight, measured 7 % slower)
         auto chunk = [&](float (&a)[CH][MT], float (&an)[CH][MT]) -> bool {
             int tn = t, sn = s0 + CH;
             if (sn >= KS) {
@@ -300,7 +293,6 @@ __device__ __forceinline__ void conv_mfma(int in_off, int out_off, const float* 
                 }
             }
             if (!more) return false;
-            if (ragged) mask_a(sn, an);
             t = tn;
             s0 = sn;
             return true;
@@ -341,11 +333,11 @@ __device__ __forceinline__ void conv_mfma_nt(int in_off, int out_off, const floa
 // output channels, toy networks) stay on the vector ALU.
 __device__ __noinline__ void conv_lds(const float* in, float* out, const float* __restrict__ Wt, int Cin, int CoutPad, int Cout, int taps,
                          const short* nb, int HW, bool accumulate) {
-    if ((Cout & 15) == 0 && CoutPad == Cout && HW <= 16 * MAXNT) {
+    if (fp32_conv_on_mfma(Cout, CoutPad, HW)) {
         const int io = (int)(in - lds_f32), oo = (int)(out - lds_f32);
         const int no = (int)(reinterpret_cast<const float*>(nb) - lds_f32);
         const int zo = no + (9 * HW + 1) / 2;   // the zero word behind the neighbour table (k_net_fp32 clears it)
-        if (Cout >= 128) conv_mfma_nt<2>(io, oo, Wt, Cin, Cout, taps, no, zo, HW, accumulate);
+        if ((Cout & 31) == 0 && Cout >= 128) conv_mfma_nt<2>(io, oo, Wt, Cin, Cout, taps, no, zo, HW, accumulate);
         else conv_mfma_nt<1>(io, oo, Wt, Cin, Cout, taps, no, zo, HW, accumulate);
     } else {
         conv_valu(in, out, Wt, Cin, CoutPad, Cout, taps, nb, HW, accumulate);
