@@ -90,16 +90,31 @@ __device__ __forceinline__ Best wave_best(Best v) {
 struct SumPair {
     double kahan, simple;
 };
+// The chain itself is what the JDK does, term after term; only the LDS reads run ahead of it: eight terms (and their eight
+// `use` bytes, one 64-bit read - `use` is 8-byte aligned) are requested together, so a read's latency is paid once per eight
+// terms instead of once per term (k_backup: 150 -> see DESIGN.md §4).
 __device__ __forceinline__ SumPair java_sum_lds(const double* t, const unsigned char* use, int n) {
     double sum = 0.0, comp = 0.0, simple = 0.0;
-    for (int j = 0; j < n; j++) {
-        if (use && !use[j]) continue;
-        double d = t[j];
+    auto step = [&](double d) {
         double tmp = d - comp;
         double velvel = sum + tmp;
         comp = (velvel - sum) - tmp;
         sum = velvel;
         simple += d;
+    };
+    int j = 0;
+    for (; j + 8 <= n; j += 8) {
+        double d[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) d[k] = t[j + k];
+        const unsigned long long um = use ? *reinterpret_cast<const unsigned long long*>(use + j) : ~0ull;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if ((um >> (8 * k)) & 0xffull) step(d[k]);
+    }
+    for (; j < n; j++) {
+        if (use && !use[j]) continue;
+        step(t[j]);
     }
     double r = sum - comp;
     SumPair out;
@@ -533,7 +548,7 @@ __global__ __launch_bounds__(W) void k_backup(TreeParams P, TreeStore T, NetOut 
     __shared__ double s_a[kMaxActions];
     __shared__ double s_b[kMaxActions];
     __shared__ double s_c[kMaxActions];
-    __shared__ unsigned char s_use[kMaxActions];
+    __shared__ __attribute__((aligned(8))) unsigned char s_use[kMaxActions];
     __shared__ unsigned char s_sel[kMaxM];
 
     const int sim = S->sims_run;

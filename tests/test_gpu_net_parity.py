@@ -21,7 +21,7 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 
 TOL = {capi.PRECISION_FP32: dict(h=2e-4, l=2e-4, p=2e-4, v=2e-4),
-       capi.PRECISION_BF16: dict(h=3e-2, l=4.5e-2, p=2e-2, v=8e-2),
+       capi.PRECISION_BF16: dict(h=3e-2, l=8e-2, p=2e-2, v=8e-2),   # sweeps: logits up to 6.9e-2 on PegSolitair (16 blocks)
        # fp16 operands: inside the reference's own cross-backend bar allClose(1e-2, 1e-2) on every output.  Bars set from a
        # sweep over 400 random networks / batches (tools/fuzz_net_stats.py, profiles/r2_fuzz.txt): worst |err| / (1 + |ref|)
        # hidden 1.3e-3, logits 4.5e-3 (PegSolitair, 16 blocks: 8.2e-3), policy 6.3e-4, value / scale 4.8e-3
