@@ -273,7 +273,6 @@ __global__ __launch_bounds__(W) void k_root(TreeParams P, TreeStore T, const uin
     __shared__ unsigned char s_sel[kMaxActions];
     __shared__ int s_action[kMaxActions];
     __shared__ double s_t0[kMaxActions];
-    __shared__ double s_t1[kMaxActions];
     __shared__ int s_cnt[64];
     __shared__ int s_T;
     GameState* S = &T.gs[g];
