@@ -146,6 +146,7 @@ struct HeadDev {
 // Byte offsets into the workgroup's one dynamic LDS array.
 struct LdsPlan {
     int img_off, zrow_off, zbytes, zstride, ring_off, tb_off, stat_off, meta_off, head_off, total;
+    int img0_off;   // the input image of conv0 (its rows are 32 B wider); = img_off except in the one-launch tower plans
     int tbs;  // TB row stride in bytes (broadcast kernel)
     int kp, qt;
 };
@@ -956,7 +957,7 @@ __device__ __forceinline__ void seg_front(Ctx& c, const Col (&k)[G::NC], const N
     using BS = BlockStages<G>;
     const int HW = d.HW;
     const int g0 = blockIdx.x * NB;
-    char* img = smem + L.img_off;
+    char* img = smem + L.img0_off;
 
     if (IN == IN_X) {
         ring.init(tw.stream + (long long)tw.foff[b0] * 64, smem + L.ring_off, c.wave, c.lane);
@@ -1012,7 +1013,9 @@ __device__ __forceinline__ void seg_front(Ctx& c, const Col (&k)[G::NC], const N
                 }
             }
         }
+        c.L.img_off = L.img0_off;   // conv0 reads its own image; everything behind it the block images at img_off
         conv_lds<G, KS0, 9, G::NRC, NRCW, RS0>(c, k, ring, X, b0 < b1 ? BS::open0 : 0, b0 < b1 ? BS::open1 : 0);
+        c.L.img_off = L.img_off;
     }
 
 }
@@ -1412,6 +1415,29 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_tower(NetDims d, TowerDev tw,
     seg_rest<G, OUT>(c, k, d, tw, hd, io, L, smem, ring, X, NB, b0, b1);
 }
 
+// The same for a tower with two broadcast blocks (blk and blk2; PegSolitair: 16 blocks, every eighth a broadcast block).
+template <class G, int IN, int KSB, int OUT>
+__global__ __launch_bounds__(G::NT, G::WPE) void k_tower2(NetDims d, TowerDev tw, HeadDev hd, NetIO io, LdsPlan L, int NB, int blk,
+                                               int blk2, int b1) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NRCW = G::NRCW, NC = G::NC;
+    using BS = BlockStages<G>;
+    Ctx c;
+    ctx_init<G>(c, smem, L, d, NB);
+    Col k[NC];
+    if (!setup<IN, NC>(d, io, NB, c, k)) return;
+    WRing<G::NW, G::SM> ring;
+    f32x16 X[NRCW][NC];
+    seg_front<G, IN>(c, k, d, tw, io, L, smem, ring, X, NB, 0, blk);
+    seg_rest<G, OUT_REGS>(c, k, d, tw, hd, io, L, smem, ring, X, NB, 0, blk);
+    const int b0 = blk + 1;
+    bcast_body<G, KSB, true>(c, k, tw, io, L, smem, ring, X, NB, blk, b0 < blk2 ? BS::open0 : 0, b0 < blk2 ? BS::open1 : 0);
+    seg_rest<G, OUT_REGS>(c, k, d, tw, hd, io, L, smem, ring, X, NB, b0, blk2);
+    const int b2 = blk2 + 1;
+    bcast_body<G, KSB, true>(c, k, tw, io, L, smem, ring, X, NB, blk2, b2 < b1 ? BS::open0 : 0, b2 < b1 ? BS::open1 : 0);
+    seg_rest<G, OUT>(c, k, d, tw, hd, io, L, smem, ring, X, NB, b2, b1);
+}
+
 template <class G, int KSB, int OUT>
 __global__ __launch_bounds__(G::NT, G::WPE) void k_bseg(NetDims d, TowerDev tw, HeadDev hd, NetIO io, LdsPlan L, int NB, int blk,
                                              int b0, int b1) {
@@ -1551,15 +1577,17 @@ LdsPlan make_plan_seg(const NetDims& d, int COLS, int NW, int SM) {
     // the ring comes first: LDS-DMA destinations stay below 64 KiB
     L.ring_off = 0;
     L.img_off = NSLOT * SM * 1024;
+    L.img0_off = L.img_off;
     int end = L.img_off + align16(COLS * rs0);
     L.head_off = 0;
     plan_tail(L, end, NW, d.Cb);
     return L;
 }
-// k_bcast: [region 2 = ring / TB][image, C channels]
+// k_bcast: [region 2 = ring / TB][image, C channels].  with_conv0 (the one-launch towers): conv0's wider input image lies
+// right behind the ring, over the tail of the TB region and the block image - both are dead while conv0 runs.
 LdsPlan make_plan_bcast(const NetDims& d, int COLS, int NB, int NW, int SM, bool with_conv0 = false) {
     LdsPlan L{};
-    const int rsc = with_conv0 ? (d.C + 16) * 2 + 16 : d.C * 2 + 16;
+    const int rsc = d.C * 2 + 16, rs0 = (d.C + 16) * 2 + 16;
     L.kp = (d.HW + 15) / 16 * 16;
     L.qt = (d.HW + 31) / 32;
     L.tbs = (NB * L.kp + 8) * 2;
@@ -1567,7 +1595,10 @@ LdsPlan make_plan_bcast(const NetDims& d, int COLS, int NB, int NW, int SM, bool
     L.ring_off = 0;
     L.tb_off = 0;
     L.img_off = ring > tbb ? ring : tbb;
-    plan_tail(L, L.img_off + align16(COLS * rsc), NW, d.Cb);
+    L.img0_off = with_conv0 ? ring : L.img_off;
+    int end = L.img_off + align16(COLS * rsc);
+    if (with_conv0 && L.img0_off + align16(COLS * rs0) > end) end = L.img0_off + align16(COLS * rs0);
+    plan_tail(L, end, NW, d.Cb);
     return L;
 }
 
@@ -1814,6 +1845,20 @@ bool try_launch_tower(MfmaNet* n, hipStream_t st, int grid, const NetDims& d, co
         }
     }
 }
+// two broadcast blocks in one launch: instantiated for numChannels 128 on 49-cell boards (PegSolitair)
+template <class G, int IN>
+bool try_launch_tower2(MfmaNet* n, hipStream_t st, int grid, const NetDims& d, const TowerDev& tw, const NetIO& io, int blk,
+                       int blk2) {
+    if constexpr (G::NC != 1 || G::C != 128) {
+        return false;
+    } else {
+        if (n->Ltw.total > 160 * 1024 || n->Lbc.kp / 16 != 4) return false;
+        lds_optin(reinterpret_cast<const void*>(&k_tower2<G, IN, 4, OUT_FINAL>));
+        hipLaunchKernelGGL((k_tower2<G, IN, 4, OUT_FINAL>), dim3(grid), dim3(G::NT), n->Ltw.total, st, d, tw, n->hd, io, n->Ltw,
+                           n->NB, blk, blk2, d.R);
+        return true;
+    }
+}
 template <class G, int OUT>
 void launch_bseg_k(MfmaNet* n, hipStream_t st, int grid, const NetDims& d, const TowerDev& tw, const NetIO& io, int blk, int b0,
                    int b1) {
@@ -1857,6 +1902,15 @@ int forward_t(MfmaNet* n, hipStream_t st, bool initial, const NetDims& d, const 
                          : try_launch_tower<G, IN_HIDDEN>(n, st, grid, d, tw, io, e))) {
                 hipLaunchKernelGGL(k_heads, dim3((io.B + HS - 1) / HS), dim3(HT), heads_lds_bytes(d), st, d, n->hd, io);
                 return 0;
+            }
+            if (tower && e2 < d.R) {   // exactly two broadcast blocks
+                int e3 = e2 + 1;
+                while (e3 < d.R && tw.type[e3] == 0) e3++;
+                if (e3 == d.R && (initial ? try_launch_tower2<G, IN_OBS>(n, st, grid, d, tw, io, e, e2)
+                                          : try_launch_tower2<G, IN_HIDDEN>(n, st, grid, d, tw, io, e, e2))) {
+                    hipLaunchKernelGGL(k_heads, dim3((io.B + HS - 1) / HS), dim3(HT), heads_lds_bytes(d), st, d, n->hd, io);
+                    return 0;
+                }
             }
         }
         if (initial) {
