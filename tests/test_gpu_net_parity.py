@@ -129,6 +129,7 @@ def test_f16_mfma_forward_matches_oracle(name):
 
 @pytest.mark.parametrize("env,name", [({"MZ_FUSE": "0"}, "go9"), ({"MZ_FUSE": "1"}, "go9"),
                                       ({"MZ_FUSE": "0"}, "pegsolitair"), ({"MZ_FUSE": "1"}, "go5"),
+                                      ({"MZ_FUSE": "1"}, "pegsolitair"),   # k_seg -> k_bseg -> k_bseg (default: k_tower2)
                                       ({"MZ_GEOM": "1"}, "go9"), ({"MZ_GEOM": "1", "MZ_FUSE": "0"}, "pegsolitair")])
 def test_bf16_alternative_launch_chains_and_geometry(env, name, monkeypatch):
     """The diagnostic variants kept for A/B runs meet the same tolerance: separate k_seg / k_bcast
