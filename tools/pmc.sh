@@ -14,8 +14,9 @@ P2="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_L
 P3="FETCH_SIZE"
 P4="WRITE_SIZE"
 P5="GRBM_GUI_ACTIVE"
+P6="TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"
 i=0
-for P in "$P1" "$P2" "$P3" "$P4" "$P5"; do
+for P in "$P1" "$P2" "$P3" "$P4" "$P5" "$P6"; do
   i=$((i+1))
   timeout -s KILL 120 rocprofv3 --pmc $P --output-format csv -d $OUT/p$i -- python3 $GRAFT_REPO_ROOT/tools/bench_net.py --workload $WL --games $GAMES --iters 3 --precision $PREC > $OUT/p$i.log 2>&1
 done
@@ -23,7 +24,7 @@ python3 - <<PY > $OUT/summary.txt
 import csv, glob, collections, json, re
 print("# per-dispatch averages over the recurrentInference launches of tools/bench_net.py --workload $WL --games $GAMES --precision $PREC (rocprofv3 --pmc, one pass per counter group)")
 traffic = {"fetch": {}, "write": {}}
-for i in (1, 2, 3, 4, 5):
+for i in (1, 2, 3, 4, 5, 6):
     fs = glob.glob("$OUT/p%d/**/*counter_collection.csv" % i, recursive=True)
     agg = collections.defaultdict(lambda: collections.defaultdict(float)); disp = collections.defaultdict(set)
     for f in fs:
