@@ -123,6 +123,7 @@ struct TowerDev {
     const u32x4* gb;       // LayerNorm gamma/beta, fp16: per LN [rt][qd][h][HW+1]{g0..3,b0..3}
     const u32x4* wbf;      // broadcast-linear B fragments (bf16)
     const float* bb;       // broadcast-linear bias, padded to QT*32
+    const float* wact;     // dynamics: conv0's weights on the action planes, fp32 [a][9][C] (see seg_front)
     int type[kMaxResiduals];
     int foff[kMaxResiduals];         // first fragment of the block in the stream
     long long gboff[kMaxResiduals];  // in u32x4 units
@@ -951,7 +952,9 @@ __device__ __forceinline__ void seg_front(Ctx& c, const Col (&k)[G::NC], const N
                                           const LdsPlan& L, char* smem, WRing<G::NW, G::SM>& ring, f32x16 (&X)[G::NRCW][G::NC],
                                           int NB, int b0, int b1) {
     constexpr int C = G::C, NRCW = G::NRCW, NC = G::NC;
-    constexpr int CIN0 = IN == IN_OBS ? 32 : C + 16;  // input channels of conv0, padded to 16
+    // input channels of conv0 on the matrix cores, padded to 16: the observation planes, or the C channels of the parent
+    // state - the dynamics net's one-hot action planes are added afterwards (below)
+    constexpr int CIN0 = IN == IN_OBS ? 32 : C;
     constexpr int KS0 = CIN0 / 16;
     constexpr int RS0 = CIN0 * 2 + 16;
     using BS = BlockStages<G>;
@@ -1000,22 +1003,38 @@ __device__ __forceinline__ void seg_front(Ctx& c, const Col (&k)[G::NC], const N
                     for (int i = 0; i < 16; i++) y[i] = X[rt][ct][i];
                     img_store(img, RS0, k[ct].col, c.wr * NRCW + rt, c.h, y);
                 }
-                // ConcatInputsBlock: the one-hot action planes as channels C .. C+a-1 (padded to 16)
-                if (c.wr == 0) {
-                    const int cell = c.meta[3 * MAXNB + (k[ct].valid ? k[ct].board : 0)];
-                    float y[8];
-#pragma unroll
-                    for (int i = 0; i < 8; i++) {
-                        const int pl = 8 * c.h + i;
-                        y[i] = (k[ct].live && pl < d.a && cell == pl * HW + k[ct].p) ? 1.f : 0.f;
-                    }
-                    *reinterpret_cast<bf16x8*>(img + k[ct].col * RS0 + (C + 8 * c.h) * 2) = pack8(&y[0]);
-                }
             }
         }
         c.L.img_off = L.img0_off;   // conv0 reads its own image; everything behind it the block images at img_off
         conv_lds<G, KS0, 9, G::NRC, NRCW, RS0>(c, k, ring, X, b0 < b1 ? BS::open0 : 0, b0 < b1 ? BS::open1 : 0);
         c.L.img_off = L.img_off;
+        if (IN == IN_HIDDEN) {
+            // ConcatInputsBlock + conv0 on the action planes: plane pl is one-hot at cell q (action cell = pl * HW + q, -1 =
+            // none), so its share of conv0 is W[o][C + pl][t] at the one cell p with p + d(t) = q, per tap: a rank-1 update
+            // in exact fp32 instead of a ninth k-step per tap on the matrix cores (11 % of conv0's MFMAs and weight bytes).
+#pragma unroll
+            for (int ct = 0; ct < NC; ct++) {
+                const int cell = c.meta[3 * MAXNB + (k[ct].valid ? k[ct].board : 0)];
+                if (k[ct].live && cell >= 0) {
+                    const int pl = cell / HW, q = cell - pl * HW;
+                    int tstar = -1;
+#pragma unroll
+                    for (int t = 0; t < 9; t++)
+                        if (((k[ct].nbmask >> t) & 1u) && k[ct].p + (t / 3 - 1) * c.Wd + (t % 3 - 1) == q) tstar = t;
+                    if (tstar >= 0 && pl < d.a) {
+                        const float* wa = tw.wact + ((size_t)pl * 9 + tstar) * C;
+#pragma unroll
+                        for (int rt = 0; rt < NRCW; rt++)
+#pragma unroll
+                            for (int qd = 0; qd < 4; qd++) {
+                                const f32x4 w = *reinterpret_cast<const f32x4*>(wa + 32 * (c.wr * NRCW + rt) + 8 * qd + 4 * c.h);
+#pragma unroll
+                                for (int e = 0; e < 4; e++) X[rt][ct][4 * qd + e] += w[e];
+                            }
+                    }
+                }
+            }
+        }
     }
 
 }
@@ -1485,13 +1504,15 @@ struct FragWriter {
 };
 
 // conv W[Cout][Cin][taps]: fragment order (tap, ks, ro) with natural k; ks runs to cin_pad/16
-void pack_conv(FragWriter& fw, const float* W, int Cout, int Cin, int taps, int cin_pad) {
+// (cin_use < Cin: only the first cin_use input channels of the tensor are packed)
+void pack_conv(FragWriter& fw, const float* W, int Cout, int Cin, int taps, int cin_pad, int cin_use = -1) {
+    if (cin_use < 0) cin_use = Cin;
     for (int t = 0; t < taps; t++)
         for (int ks = 0; ks < cin_pad / 16; ks++)
             for (int ro = 0; ro < Cout / 32; ro++)
                 fw.frag([&](int row, int kp) {
                     const int ci = 16 * ks + kp;
-                    if (ci >= Cin) return 0.f;
+                    if (ci >= cin_use) return 0.f;
                     return W[((size_t)(32 * ro + row) * Cin + ci) * taps + t];
                 });
 }
@@ -1520,7 +1541,7 @@ void pack_gb(std::vector<unsigned short>& out, const float* g, const float* b, i
 
 struct TowerHost {
     std::vector<unsigned short> stream, gb, wbf;
-    std::vector<float> bb;
+    std::vector<float> bb, wact;
     TowerDev dev{};
 };
 
@@ -1573,7 +1594,7 @@ void plan_tail(LdsPlan& L, int end, int NW, int Cb) {
 // k_seg: [ring][image]
 LdsPlan make_plan_seg(const NetDims& d, int COLS, int NW, int SM) {
     LdsPlan L{};
-    const int rs0 = (d.C + 16) * 2 + 16;
+    const int rs0 = d.C * 2 + 16;
     // the ring comes first: LDS-DMA destinations stay below 64 KiB
     L.ring_off = 0;
     L.img_off = NSLOT * SM * 1024;
@@ -1587,7 +1608,7 @@ LdsPlan make_plan_seg(const NetDims& d, int COLS, int NW, int SM) {
 // right behind the ring, over the tail of the TB region and the block image - both are dead while conv0 runs.
 LdsPlan make_plan_bcast(const NetDims& d, int COLS, int NB, int NW, int SM, bool with_conv0 = false) {
     LdsPlan L{};
-    const int rsc = d.C * 2 + 16, rs0 = (d.C + 16) * 2 + 16;
+    const int rsc = d.C * 2 + 16, rs0 = d.C * 2 + 16;
     L.kp = (d.HW + 15) / 16 * 16;
     L.qt = (d.HW + 31) / 32;
     L.tbs = (NB * L.kp + 8) * 2;
@@ -1698,12 +1719,19 @@ int mfma_pack_weights(MfmaNet* n, const NetDims& d, const float* blob, size_t co
     };
     TowerHost th[2];
     const int cin0[2] = {d.O, C + d.a};
-    const int cin0_pad[2] = {32, C + 16};
+    const int cin0_pad[2] = {32, C};   // dynamics: the C hidden-state channels; the action planes go through TowerDev::wact
     for (int t = 0; t < 2; t++) {
         TowerHost& T = th[t];
         FragWriter fw{T.stream};
         const float* w0 = take((size_t)C * cin0[t] * 9);
-        pack_conv(fw, w0, C, cin0[t], 9, cin0_pad[t]);
+        pack_conv(fw, w0, C, cin0[t], 9, cin0_pad[t], t == 0 ? cin0[t] : C);
+        if (t == 1) {
+            T.wact.assign((size_t)d.a * 9 * C, 0.f);
+            for (int pl = 0; pl < d.a; pl++)
+                for (int tap = 0; tap < 9; tap++)
+                    for (int o = 0; o < C; o++)
+                        T.wact[((size_t)pl * 9 + tap) * C + o] = w0[((size_t)o * cin0[t] + C + pl) * 9 + tap];
+        }
         for (int i = 0; i < d.R; i++) {
             const bool bc = d.bcast_every_n > 0 && (i % d.bcast_every_n == d.bcast_every_n - 1);
             T.dev.type[i] = bc ? 1 : 0;
@@ -1772,6 +1800,11 @@ int mfma_pack_weights(MfmaNet* n, const NetDims& d, const float* blob, size_t co
         if (th[t].bb.empty()) th[t].bb.assign(128, 0.f);
         if (upload(n, th[t].bb, &p, 64, err)) return -1;
         th[t].dev.bb = (const float*)p;
+        th[t].dev.wact = nullptr;
+        if (!th[t].wact.empty()) {
+            if (upload(n, th[t].wact, &p, 64, err)) return -1;
+            th[t].dev.wact = (const float*)p;
+        }
         n->tw[t] = th[t].dev;
     }
     // fp32 head parameters
