@@ -1,26 +1,38 @@
-// bf16 MFMA forward of initialInference (f o h) and recurrentInference (f o g) for gfx950.
+// EXPERIMENT, not built into the library (round 3): the tower on v_mfma_f32_16x16x32 - parity-green, 3-5 % slower than the
+// product kernel; results and the reasons in profiles/r3_shape_tower.txt.  Build as an A/B library with tools/experiments/build16.sh.
+// 16-bit MFMA forward of initialInference (f o h) and recurrentInference (f o g) for gfx950.
 //
 // One 512-thread workgroup (8 wavefronts = 2 per SIMD, <= 256 VGPRs each) carries a tile of NB whole
 // boards through a run of layers in one launch.  Every conv is the transposed GEMM
 //     Y[out-channel][column] = W[out-channel][k] * Act[k][column],   column = (board, cell),
-// on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
-//   * The waves form a WR x WC grid (WR*WC = 8): wave (wr, wc) owns the 32 columns 32*wc .. 32*wc+31 and
-//     the 1/WR share of the channels; the fp32 residual stream X (4 row tiles = 64 registers) and the
-//     bottleneck activations (2 row tiles) stay in that wave's registers for the whole run, and the
-//     closing 1x1 conv of a block accumulates straight into X.  numChannels 128 uses WR = 1 (256 columns
-//     per workgroup), numChannels 256 uses WR = 2 (128 columns): the same register footprint.
+// on v_mfma_f32_16x16x32_{f16,bf16} with fp32 accumulation (round 3: the 16x16x32 shape holds a higher clock than
+// 32x32x16 on this power-limited chip at the same output tile per wave - tools/micro/convloop.hip,
+// profiles/r3_convloop_micro.txt: 2144 against 1701 TFLOP/s for the 3x3-conv loop).
+//   * The waves form a WR x WC grid (WR*WC = 8): wave (wr, wc) owns the 32 columns 32*wc .. 32*wc+31 (two 16-column
+//     tiles) and the 1/WR share of the channels (row tiles of 16); lane (r = lane & 15, q = lane >> 4) holds, per
+//     (row tile t, column tile j), the four channels 16t + 4q + 0..3 of column 16j + r.  The fp32 residual stream X
+//     (8 x 2 tiles = 64 registers) and the bottleneck activations (4 x 2 tiles) stay in that wave's registers for the
+//     whole run, and the closing 1x1 conv of a block accumulates straight into X.  numChannels 128 uses WR = 1 (256
+//     columns per workgroup), numChannels 256 uses WR = 2 (128 columns): the same register footprint.
 //   * Two waves per SIMD is the point of the layout: LayerNorm is VALU work (statistics, normalise,
 //     pack) between the matrix phases; one wave's VALU issues beside the other's MFMAs, a single
 //     wave per SIMD issues a VALU instruction only every 4 cycles, and with <= 256 registers the
 //     accumulators are ordinary VGPRs (no v_accvgpr moves around every VALU use).
-//   * Every conv reads its B operand (activations after LayerNorm + ReLU, bf16) from a [column][channel]
-//     image in LDS: 1x1 convs from the wave's own columns, 3x3 convs through 9 shifted neighbour rows
-//     (a zero row for off-board cells) - the implicit GEMM, never materialised.
-//   * Weights are packed on the host into 1 KiB MFMA A-fragments in exact execution order, one linear
-//     stream per tower.  The workgroup streams them global -> LDS with global_load_lds_dwordx4 (no
+//   * Every conv reads its B operand (activations after LayerNorm + ReLU, 16-bit) from a [column][channel] image in
+//     LDS: 1x1 convs from the wave's own columns, 3x3 convs through 9 shifted neighbour rows (a zero row for
+//     off-board cells) - the implicit GEMM, never materialised.  Image rows are 2 * channels + 32 bytes apart and the
+//     16-byte chunk index is XORed with bit 2 of the row index: with that, both the ds_read_b128 of a 16x16x32 B
+//     operand (lane groups of MI355X_MICROARCH.md, LDS table) and the ds_write_b128 of the LayerNorm output are free of
+//     bank conflicts (a plain 2 * channels + 16 stride is 2-way on either).  Channels sit in a row in the order the
+//     writing lanes hold them (wave row, q, row tile, e): a lane's eight values of two row tiles are one 16-byte store;
+//     the A fragments are packed on the host in the matching k order.
+//   * Weights are packed on the host into 1 KiB MFMA A-fragments (16 output channels x 32 k) in exact execution
+//     order, one linear stream per tower.  The workgroup streams them global -> LDS with global_load_lds_dwordx4 (no
 //     registers) into a three-slot ring, two stages ahead; a slot holds one stage (<= 24 fragments) that
 //     all 8 waves read with ds_read_b128.  One barrier per stage publishes the slot that was requested
-//     two stages ago and frees the one just computed for the next prefetch.
+//     two stages ago and frees the one just computed for the next prefetch.  Inside a conv the operand look-ahead
+//     runs across those barriers (the next stage's slot is already published), and a k-step's reads are dealt out
+//     between the previous k-step's MFMAs, so the matrix pipe does not drain at a stage boundary.
 //   * On single-row wave grids the 1x1 convs of a bottleneck block skip the image: the LayerNorm output, packed in
 //     accumulator order, IS the B operand (ln_to_regs / conv_regs; A fragments packed in the matching k order).
 //   * The prediction heads: their three 1x1 convs are taken off X in registers by the tower's last launch (3 floats per
@@ -41,7 +53,7 @@
 // -DMZ_F16=1 -> fp16 operands (11-bit significand: 8x smaller rounding error at the same matrix rate; the operands here
 // are LayerNorm outputs, [0, 1] hidden states, 0/1 planes and O(1) weights, far inside fp16's range, and gfx950's MFMA
 // keeps fp16 subnormals).  Everything else - tiling, LDS layout, fp32 accumulation, fp16 gamma/beta - is shared.
-#include "net_mfma.h"
+#include "../../muzero_amd/csrc/net_mfma.h"
 
 #include <math.h>
 
@@ -77,16 +89,14 @@ namespace MZ_IMPL {
 #if MZ_F16
 typedef _Float16 op_t;   // MFMA operand element
 #define MZ_CVT_PK "v_cvt_pk_f16_f32"
-#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
 #else
 typedef __bf16 op_t;
 #define MZ_CVT_PK "v_cvt_pk_bf16_f32"
-#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 #endif
-typedef __attribute__((ext_vector_type(8))) op_t bf16x8;   // (the names predate the fp16 variant: 8 / 4 operand elements)
-typedef __attribute__((ext_vector_type(4))) op_t bf16x4;
+typedef __attribute__((ext_vector_type(8))) op_t opx8;   // one lane's share of an MFMA A or B operand
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
@@ -95,15 +105,20 @@ typedef __attribute__((ext_vector_type(2))) short s16x2;
 
 constexpr int MAXNB = 32;    // boards per workgroup upper bound (256 / 9 = 28)
 // Zero rows that off-board 3x3 neighbours read.  One shared row would put every off-board lane of a ds_read_b128 on the
-// banks of some on-board lane of its 16-lane group (the 16 image rows of a group tile all 64 banks exactly): +1 LDS cycle
-// per group on most taps (PMC: SQ_LDS_BANK_CONFLICT was a sixth of SQ_LDS_IDX_ACTIVE, 58 % less with this).  Instead
+// banks of some on-board lane of its 16-lane group (the 16 image rows of a group tile all 64 banks exactly).  Instead
 // there are 16 zero rows at the image's row stride, starting at the image's phase (mod 256 B): a lane reads zero row
-// (row index mod 16), which lies on the very banks its on-board read would have used (16 * RS is a multiple of 256 B
-// for every RS = 2C + 16).  Served that way: the bottleneck images (row stride 2 Cb + 16: the 3x3 convs c2 / c3, two
-// thirds of all MFMAs); the wider images of conv0 read zero row 0 only.  LdsPlan::zbytes = ZROWS * (2 Cb + 16).
+// (row index mod 16) with the row's own chunk swizzle, which lies on the very banks its on-board read would have used
+// (16 * RS is a multiple of 256 B for every RS = 2C + 32).  Served that way: the bottleneck images (row stride 2 Cb + 32:
+// the 3x3 convs c2 / c3, two thirds of all MFMAs); the wider images of conv0 read zero row 0 only.
+// LdsPlan::zbytes = ZROWS * (2 Cb + 32).
 constexpr int ZROWS = 16;
 
-#if defined(MZ_STAMPS)  // diagnostic build: per-phase cycle counts of workgroup 0 (waves 0 and 7), printed by the kernel
+#if defined(MZ_TL)   // diagnostic build: absolute timeline of one bottleneck block (workgroup 0, waves 0 and 4)
+__device__ unsigned long long g_tl[8 * 96 * 2];
+#define STAMP(c, i) do { if ((c).tl_on) { if ((c).lane == 0 && (c).tl_n < 96) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); g_tl[((c).wave * 96 + (c).tl_n) * 2] = t_; g_tl[((c).wave * 96 + (c).tl_n) * 2 + 1] = (i); } (c).tl_n++; } } while (0)
+#define STAMP_PRINT(c, name) do { if (blockIdx.x == 0 && (c).lane == 0 && ((c).wave == 0 || (c).wave == 4)) for (int i_ = 0; i_ < (c).tl_n && i_ < 96; i_++) \
+    printf("TL w%d %d id %d t %llu\n", (c).wave, i_, (int)g_tl[((c).wave * 96 + i_) * 2 + 1], g_tl[((c).wave * 96 + i_) * 2] - g_tl[((c).wave * 96) * 2]); } while (0)
+#elif defined(MZ_STAMPS)  // diagnostic build: per-phase cycle counts of workgroup 0 (waves 0 and 7), printed by the kernel
 #define STAMP(c, i) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); (c).st_acc[i] += (unsigned)(t_ - (c).st_last); (c).st_last = t_; } while (0)
 #define STAMP_PRINT(c, name) do { if (blockIdx.x == 0 && ((c).wave == 0 || (c).wave == 2 || (c).wave == 4 || (c).wave == 7) && (c).lane == 0) \
     printf("%s w%d: stats %u norm %u acquire %u mma %u xload %u xstore %u rescale %u head %u other %u bcast %u | hconv %u hln %u hfc %u | sbar %u scomb %u\n", name, (c).wave, \
@@ -120,9 +135,9 @@ enum { OUT_X = 0, OUT_FINAL = 1, OUT_REGS = 2 };   // OUT_REGS: X stays in regis
 
 struct TowerDev {
     const u32x4* stream;   // A fragments in execution order
-    const u32x4* gb;       // LayerNorm gamma/beta, fp16: per LN [rt][qd][h][HW+1]{g0..3,b0..3}
-    const u32x4* wbf;      // broadcast-linear B fragments (bf16)
-    const float* bb;       // broadcast-linear bias, padded to QT*32
+    const u32x4* gb;       // LayerNorm gamma/beta, fp16: per LN [channel quad][HW+1]{g0..3,b0..3}
+    const u32x4* wbf;      // broadcast-linear B fragments (16-bit)
+    const float* bb;       // broadcast-linear bias, padded to QT*16
     const float* wact;     // dynamics: conv0's weights on the action planes, fp32 [a][9][C] (see seg_front)
     int type[kMaxResiduals];
     int foff[kMaxResiduals];         // first fragment of the block in the stream
@@ -147,22 +162,22 @@ struct HeadDev {
 // Byte offsets into the workgroup's one dynamic LDS array.
 struct LdsPlan {
     int img_off, zrow_off, zbytes, zstride, ring_off, tb_off, stat_off, meta_off, head_off, total;
-    int img0_off;   // the input image of conv0 (its rows are 32 B wider); = img_off except in the one-launch tower plans
+    int img0_off;   // the input image of conv0; = img_off except in the one-launch tower plans
     int tbs;  // TB row stride in bytes (broadcast kernel)
     int kp, qt;
 };
 
-// Workgroup geometry: NW waves as a WR x WC grid, each wave owning NC column tiles of 32 columns; ring slots of SM
-// fragments (KiB); WPE = waves per SIMD the register budget is cut for.
+// Workgroup geometry: NW waves as a WR x WC grid, each wave owning NC column tiles of 32 columns (NCL = 2 NC tiles of 16:
+// a lane holds one column of each); ring slots of SM fragments (KiB); WPE = waves per SIMD the register budget is cut for.
 template <int C_, int CB_, int WR_, int NW_, int SM_, int WPE_, int NC_ = 1>
 struct Geo {
     static constexpr int C = C_, CB = CB_, WR = WR_, NW = NW_, SM = SM_, WPE = WPE_, NC = NC_;
     static constexpr int NT = 64 * NW;
-    static constexpr int WC = NW / WR, COLS = 32 * WC * NC;
+    static constexpr int WC = NW / WR, COLS = 32 * WC * NC, NCL = 2 * NC;
     static_assert(NW % WR == 0 && NW % 2 == 0, "wave grid");
-    static constexpr int NRC = C / 32, NRB = CB / 32;       // row tiles of the whole layer
-    static constexpr int NRCW = NRC / WR, NRBW = NRB / WR;  // row tiles one wave owns
-    static_assert(NRC % WR == 0 && NRB % WR == 0 && NRBW >= 1, "channel split");
+    static constexpr int NTC = C / 16, NTB = CB / 16;       // row tiles (16 channels) of the whole layer
+    static constexpr int NTCW = NTC / WR, NTBW = NTB / WR;  // row tiles one wave owns
+    static_assert(NTC % WR == 0 && NTB % WR == 0 && NTBW >= 2 && NTCW % 2 == 0 && NTBW % 2 == 0, "channel split");
 };
 
 // Stage split of a conv with KK k-steps of NROT fragments: equal stages of SK k-steps, <= SM fragments.
@@ -185,21 +200,8 @@ constexpr int NSLOT = 3;   // ring slots: the stage being computed + two in flig
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-__device__ __forceinline__ bf16x8 pack8(const float* y) {
-    bf16x8 r;
-#pragma unroll
-    for (int i = 0; i < 8; i++) r[i] = (op_t)y[i];
-    return r;
-}
-__device__ __forceinline__ bf16x4 pack4(const float* y) {
-    bf16x4 r;
-#pragma unroll
-    for (int i = 0; i < 4; i++) r[i] = (op_t)y[i];
-    return r;
-}
-
 struct Col {
-    int col;          // column index in the workgroup
+    int col;          // column index in the workgroup (= row of the LDS images)
     int p;            // cell within the board (0 for padded columns)
     int pz;           // p, or HW for padded columns (the all-zero gamma/beta entry)
     int board;        // board within the tile (MAXNB for padded columns -> neutral statistics)
@@ -211,38 +213,70 @@ struct Col {
 struct Ctx {
     char* smem;
     LdsPlan L;
-    int HW, NB, Wd, lane, wave, wc, wr, h, r;
-    float* wpart;    // [2][MAXNB][8 waves][2] per-wave board partials (double buffered)
+    int HW, NB, Wd, lane, wave, wc, wr, q, r;
+    float* wpart;    // [2][NB][8 waves][2] per-wave board partials (double buffered)
     int parity;
+    int vm_young;    // vector-memory operations of this wave's newest ring issue (they may stay in flight across a barrier)
     int* meta;       // [4][MAXNB]: src slot, dst slot, live, action cell
-#if defined(MZ_STAMPS)
+#if defined(MZ_TL)
+    bool tl_on;
+    int tl_n;
+#elif defined(MZ_STAMPS)
     unsigned st_acc[16];
     unsigned long long st_last;
 #endif
 };
 
+// Byte offset of 16-byte chunk `chunk` in image row `row` (row stride excluded): the chunk index is XORed with bit 2 of the
+// row index (see the header comment).
+__device__ __forceinline__ int swz(int row, int chunk) { return (chunk ^ ((row >> 2) & 1)) * 16; }
+
+// s_waitcnt vmcnt(n) for a wave-uniform n (the instruction takes an immediate)
+__device__ __forceinline__ void wait_vm(int n) {
+#if defined(MZ_X_VM0)
+    n = 0;
+#endif
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
 // Three-slot LDS ring over the linear A-fragment stream, filled by LDS-DMA two stages ahead.  Protocol (all waves):
 //   issue(S0); issue(S1);  acquire() -> issue(S2) -> compute S0;  acquire() -> issue(S3) -> compute S1; ...
-// acquire() waits for this wave's own DMA (vmcnt(0): the stage due now was requested two stages ago, the next
-// one a whole stage ago), then the workgroup barrier makes every wave's part visible and proves that all waves
-// have left the slot the next issue() overwrites (the one computed before the barrier).
+// acquire() waits for this wave's own DMA of the stage due now - requested two stages ago; the pieces of the newest issue
+// (Ctx::vm_young of them, the youngest vector-memory operations of the wave) stay in flight, so a stage has two stages'
+// time to land - then the workgroup barrier makes every wave's part visible and proves that all waves have left the
+// slot the next issue() overwrites (the one computed before the barrier).
 template <int NW, int SM>
 struct WRing {
     const char* gptr;  // next fragment to load (wave-uniform)
+    const char* gbase0;
     char* lds;         // ring base
     unsigned ldsoff;   // the same as an LDS byte address (what M0 takes)
     int ld_idx, rd_idx, wave;
     unsigned lane16;
     __device__ __forceinline__ void init(const u32x4* stream, char* ring, int wave_, int lane) {
         gptr = reinterpret_cast<const char*>(stream);
+        gbase0 = gptr;
         lds = ring;
         ldsoff = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)ring;
         ld_idx = rd_idx = 0;
         wave = wave_;
         lane16 = (unsigned)lane * 16u;
     }
-    __device__ __forceinline__ void issue(int nf) {
-        if (nf == 0) return;   // nothing follows: the slot stays with the next real issue()
+    __device__ __forceinline__ void issue(Ctx& c, int nf) {
+        if (nf == 0) {   // nothing follows: the slot stays with the next real issue(), and no piece may stay in flight
+            c.vm_young = 0;
+            return;
+        }
+        c.vm_young = (nf + NW - 1 - wave) / NW;   // this wave's pieces (fragments wave, wave + NW, ...)
         // The DMA is issued from inline asm on purpose: with __builtin_amdgcn_global_load_lds in flight hipcc's
         // s_waitcnt pass turns every LDS-read wait of the MFMA loops into lgkmcnt(0), which undoes their software
         // pipelining.  M0 = LDS byte address of the fragment (wave-uniform), written in the same statement.
@@ -253,14 +287,35 @@ struct WRing {
             if (f < nf) {
                 const unsigned m0v = dst + f * 1024;
                 const char* gp = gptr + (size_t)f * 1024;   // scalar base + the lane's 32-bit offset: no vector address arithmetic
+#if defined(MZ_X_NODMA)
+                continue;
+#elif defined(MZ_X_FIXDMA)   // every stage from the same 24 KiB of the stream: perfect cache locality, wrong results
+                gp = gbase0 + (size_t)f * 1024;
+#endif
                 asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, %2" ::"v"(lane16), "s"(m0v), "s"(gp) : "memory");
             }
         }
         gptr += (size_t)nf * 1024;
         ld_idx = ld_idx == NSLOT - 1 ? 0 : ld_idx + 1;
     }
-    __device__ __forceinline__ const char* acquire() {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __device__ __forceinline__ const char* acquire(Ctx& c) {
+        wait_vm(c.vm_young);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const char* p = lds + rd_idx * (SM * 1024);
+        rd_idx = rd_idx == NSLOT - 1 ? 0 : rd_idx + 1;
+        return p;
+    }
+    // A stage boundary inside a conv: the LDS reads in flight are the look-ahead's (the image, which the barrier does not
+    // free); every read of the slot that is given up has been consumed by an MFMA already issued.
+    __device__ __forceinline__ const char* acquire_nobar(Ctx& c) {   // timing experiment only
+        wait_vm(c.vm_young);
+        const char* p = lds + rd_idx * (SM * 1024);
+        rd_idx = rd_idx == NSLOT - 1 ? 0 : rd_idx + 1;
+        return p;
+    }
+    __device__ __forceinline__ const char* acquire_x(Ctx& c) {
+        wait_vm(c.vm_young);
+        asm volatile("s_barrier" ::: "memory");
         const char* p = lds + rd_idx * (SM * 1024);
         rd_idx = rd_idx == NSLOT - 1 ? 0 : rd_idx + 1;
         return p;
@@ -292,21 +347,21 @@ __device__ __forceinline__ float wave_red(float v) {
 // Two levels, one barrier: (1) inside each wave a masked butterfly per board that the wave's 32 columns
 // touch (at most 2 boards for boards of >= 32 cells, more for small boards), lane b keeping board b's
 // value; (2) lanes < NB publish wpart[parity][board][wave] (neutral where the wave holds none of the
-// board), barrier, and every lane combines the eight wave partials of its own board.  wpart alternates
+// board), barrier, and every lane combines the eight wave partials of its own boards.  wpart alternates
 // between two buffers so the next reduction's writes cannot overtake this one's reads.
 // VM: the barrier also waits for this wave's vector-memory operations (LDS-DMA of a gamma/beta table that the other waves
 // are about to read).
-template <int MODE, int NW, int NC, bool VM = false>
-__device__ __forceinline__ void board_reduce(Ctx& c, const Col (&k)[NC], float (&a)[NC], float (&b)[NC], float n_inv) {
+template <int MODE, int NW, int NCL, bool VM = false>
+__device__ __forceinline__ void board_reduce(Ctx& c, const Col (&k)[NCL], float (&a)[NCL], float (&b)[NCL], float n_inv) {
     const float na = MODE == 0 ? 0.f : INFINITY, nb = MODE == 0 ? 0.f : -INFINITY;
-    const int bmin = (32 * NC * c.wc) / c.HW;
-    int bmax = (32 * NC * c.wc + 32 * NC - 1) / c.HW;
+    const int bmin = (16 * NCL * c.wc) / c.HW;
+    int bmax = (16 * NCL * c.wc + 16 * NCL - 1) / c.HW;
     if (bmax > c.NB - 1) bmax = c.NB - 1;
     float ma = na, mb = nb;
     for (int bd = bmin; bd <= bmax; bd++) {
         float x = na, y = nb;
 #pragma unroll
-        for (int ct = 0; ct < NC; ct++) {
+        for (int ct = 0; ct < NCL; ct++) {
             const bool in = k[ct].board == bd;
             if (MODE == 0) {
                 x += in ? a[ct] : 0.f;
@@ -328,15 +383,18 @@ __device__ __forceinline__ void board_reduce(Ctx& c, const Col (&k)[NC], float (
             mb = y;
         }
     }
-    float* wp = c.wpart + c.parity * (MAXNB * NW * 2);
+    float* wp = c.wpart + c.parity * (c.NB * NW * 2);
     c.parity ^= 1;
     if (c.lane < c.NB) *reinterpret_cast<f32x2*>(wp + (c.lane * NW + c.wave) * 2) = (f32x2){ma, mb};
     STAMP(c, ST_STATS);
-    if (VM) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else lds_barrier();
+    if (VM) wait_vm(c.vm_young);   // the table copy is older than the newest ring issue (conv_lds / conv_regs: hook, then issue)
+    lds_barrier();
     STAMP(c, ST_SBAR);
 #pragma unroll
-    for (int ct = 0; ct < NC; ct++) {
+    for (int ct = 0; ct < NCL; ct++) {
+#if defined(MZ_X_COMB1)
+        if (ct > 0) { a[ct] = a[0]; b[ct] = b[0]; continue; }
+#endif
         const int bd = k[ct].board < MAXNB ? k[ct].board : 0;
         float x = na, y = nb;
 #pragma unroll
@@ -363,17 +421,17 @@ __device__ __forceinline__ void board_reduce(Ctx& c, const Col (&k)[NC], float (
     }
 }
 
-// LayerNorm statistics of this wave's NR row tiles x own column -> per-column (mean, rstd) of the board.
-template <int NR, int NW, int NC, bool VM = false>
-__device__ __forceinline__ void ln_stats(Ctx& c, const Col (&k)[NC], const f32x16 (&v)[NR][NC], int nch, float (&mean)[NC],
-                                         float (&rstd)[NC]) {
+// LayerNorm statistics of this wave's NR row tiles x own columns -> per-column (mean, rstd) of the board.
+template <int NR, int NW, int NCL, bool VM = false>
+__device__ __forceinline__ void ln_stats(Ctx& c, const Col (&k)[NCL], const f32x4 (&v)[NR][NCL], int nch, float (&mean)[NCL],
+                                         float (&rstd)[NCL]) {
 #pragma unroll
-    for (int ct = 0; ct < NC; ct++) {
+    for (int ct = 0; ct < NCL; ct++) {
         f32x2 s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
 #pragma unroll
         for (int rt = 0; rt < NR; rt++)
 #pragma unroll
-            for (int i = 0; i < 16; i += 2) {
+            for (int i = 0; i < 4; i += 2) {
                 f32x2 x = {v[rt][ct][i], v[rt][ct][i + 1]};
                 s2 += x;
                 q2 = x * x + q2;
@@ -381,28 +439,21 @@ __device__ __forceinline__ void ln_stats(Ctx& c, const Col (&k)[NC], const f32x1
         mean[ct] = k[ct].valid ? s2.x + s2.y : 0.f;
         rstd[ct] = k[ct].valid ? q2.x + q2.y : 0.f;
     }
-    board_reduce<0, NW, NC, VM>(c, k, mean, rstd, 1.0f / (float)(nch * c.HW));
+    board_reduce<0, NW, NCL, VM>(c, k, mean, rstd, 1.0f / (float)(nch * c.HW));
 }
 
-// gamma/beta of global row tile rt for this lane's (cell, channels): 4 x 16-byte loads.
-// Table layout per LayerNorm: [rt][qd][h][HW+1] x {g0..3, b0..3} fp16, entry HW is all zero.
-__device__ __forceinline__ void gb_load(const u32x4* gb, Ctx& c, const Col& k, int rt, u32x4 (&g)[4]) {
-    const unsigned stride = (unsigned)(c.HW + 1) * 32u;  // bytes between qd
-    const unsigned off = (unsigned)(c.h * (c.HW + 1) + k.pz) * 16u + (unsigned)(rt * 4) * stride;
-#pragma unroll
-    for (int qd = 0; qd < 4; qd++)
-        g[qd] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(gb) + off + qd * stride);
-    __builtin_amdgcn_sched_barrier(0x38F);  // keep the loads here (everything but VMEM may cross)
+// gamma/beta of global row tile t (16 channels) for this lane's (cell, channels 16t + 4q + 0..3): one 16-byte load.
+// Table layout per LayerNorm: [channel quad = 4t + q][HW+1] x {g0..3, b0..3} fp16, entry HW is all zero.
+__device__ __forceinline__ void gb_load(const u32x4* gb, Ctx& c, const Col& k, int t, u32x4& g) {
+    const unsigned off = (unsigned)((4 * t + c.q) * (c.HW + 1) + k.pz) * 16u;
+    g = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(gb) + off);
 }
-
-// The same entries from a copy of the table in LDS (gtab_issue).
-__device__ __forceinline__ void gb_load_lds(const char* gtab, Ctx& c, const Col& k, int rt, u32x4 (&g)[4]) {
-    const unsigned stride = (unsigned)(c.HW + 1) * 32u;
-    const unsigned off = (unsigned)(c.h * (c.HW + 1) + k.pz) * 16u + (unsigned)(rt * 4) * stride;
-#pragma unroll
-    for (int qd = 0; qd < 4; qd++) g[qd] = *reinterpret_cast<const u32x4*>(gtab + off + qd * stride);
+// The same entry from a copy of the table in LDS (gtab_issue).
+__device__ __forceinline__ void gb_load_lds(const char* gtab, Ctx& c, const Col& k, int t, u32x4& g) {
+    const unsigned off = (unsigned)((4 * t + c.q) * (c.HW + 1) + k.pz) * 16u;
+    g = *reinterpret_cast<const u32x4*>(gtab + off);
 }
-// One LayerNorm's gamma/beta table (bytes, contiguous) global -> LDS by LDS-DMA in 1 KiB pieces dealt to the waves: the three
+// One LayerNorm's gamma/beta table (bytes, contiguous) global -> LDS by LDS-DMA in 1 KiB pieces dealt to the waves: the
 // boards of a workgroup then share one fetch of it, and the lanes read it with ds_read_b128 while the LDS is idle anyway.
 // The copy runs under a conv; the LayerNorm's statistics barrier (board_reduce<.., VM>) publishes it.
 template <int NW>
@@ -410,111 +461,124 @@ __device__ __forceinline__ void gtab_issue(Ctx& c, const u32x4* table, int bytes
     const unsigned dst = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)gtab;
     const int npieces = (bytes + 1023) >> 10;
     for (int f = c.wave; f < npieces; f += NW) {
+#if defined(MZ_X_NOGTAB)
+        continue;
+#endif
         const unsigned m0v = dst + f * 1024;
         const char* gp = reinterpret_cast<const char*>(table) + (size_t)f * 1024;
         asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, %2" ::"v"(c.lane * 16), "s"(m0v), "s"(gp) : "memory");
     }
 }
 
-// y = relu((v - mean) * rstd * gamma + beta) for the 16 accumulator rows of one row tile.
-__device__ __forceinline__ void ln_apply(const f32x16& v, float mean, float rstd, const u32x4 (&g)[4], float (&y)[16]) {
+// y = relu((v - mean) * rstd * gamma + beta) for the 4 accumulator rows of one tile.
+__device__ __forceinline__ void ln_apply(const f32x4& v, float mean, float rstd, const u32x4& g, float (&y)[4]) {
+    f16x8 hv = __builtin_bit_cast(f16x8, g);
 #pragma unroll
-    for (int qd = 0; qd < 4; qd++) {
-        f16x8 hv = __builtin_bit_cast(f16x8, g[qd]);
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            float t = (v[4 * qd + e] - mean) * rstd;
-            t = fmaf(t, (float)hv[e], (float)hv[4 + e]);
-            y[4 * qd + e] = fmaxf(t, 0.f);
-        }
+    for (int e = 0; e < 4; e++) {
+        float t = (v[e] - mean) * rstd;
+        t = fmaf(t, (float)hv[e], (float)hv[4 + e]);
+        y[e] = fmaxf(t, 0.f);
     }
 }
 
-// Packed variant: o[j] = bf16x2 of relu(LN(v)) rows (2j, 2j+1).  Per element: half a v_pk_fma_f32
-// (normalise), one v_fma_mix_f32 (fp16 gamma/beta), half a v_cvt_pk_bf16_f32 and half a v_pk_max_i16
-// (ReLU on the packed bf16 pair: a negative bf16 is a negative int16).
-__device__ __forceinline__ void ln_apply_pk(const f32x16& v, float rstd, float nmr, const u32x4 (&g)[4], unsigned (&o)[8]) {
+// Packed variant: o[j] = 16-bit pair of relu(LN(v)) rows (2j, 2j+1).  Per element: half a v_pk_fma_f32
+// (normalise), one v_fma_mix_f32 (fp16 gamma/beta), half a v_cvt_pk_*_f32 and half a v_pk_max_i16
+// (ReLU on the packed pair: a negative bf16 / fp16 is a negative int16).
+__device__ __forceinline__ void ln_apply_pk(const f32x4& v, float rstd, float nmr, const u32x4& g, unsigned (&o)[2]) {
     const f32x2 a2 = {rstd, rstd}, n2 = {nmr, nmr};
+    f16x8 hv = __builtin_bit_cast(f16x8, g);
 #pragma unroll
-    for (int qd = 0; qd < 4; qd++) {
-        f16x8 hv = __builtin_bit_cast(f16x8, g[qd]);
-#pragma unroll
-        for (int e = 0; e < 4; e += 2) {
-            f32x2 x = {v[4 * qd + e], v[4 * qd + e + 1]};
-            f32x2 t = x * a2 + n2;
-            const float y0 = fmaf(t.x, (float)hv[e], (float)hv[4 + e]);
-            const float y1 = fmaf(t.y, (float)hv[e + 1], (float)hv[4 + e + 1]);
-            unsigned pk;
-            asm(MZ_CVT_PK " %0, %1, %2" : "=v"(pk) : "v"(y0), "v"(y1));
-            s16x2 r = __builtin_elementwise_max(__builtin_bit_cast(s16x2, pk), (s16x2){0, 0});
-            o[2 * qd + e / 2] = __builtin_bit_cast(unsigned, r);
-        }
+    for (int e = 0; e < 4; e += 2) {
+        f32x2 x = {v[e], v[e + 1]};
+        f32x2 t = x * a2 + n2;
+        const float y0 = fmaf(t.x, (float)hv[e], (float)hv[4 + e]);
+        const float y1 = fmaf(t.y, (float)hv[e + 1], (float)hv[4 + e + 1]);
+        unsigned pk;
+        asm(MZ_CVT_PK " %0, %1, %2" : "=v"(pk) : "v"(y0), "v"(y1));
+        s16x2 r = __builtin_elementwise_max(__builtin_bit_cast(s16x2, pk), (s16x2){0, 0});
+        o[e / 2] = __builtin_bit_cast(unsigned, r);
     }
 }
-// 16 rows of global row tile rt, as packed bf16 pairs, into the [column][channel] image (row stride rs)
-__device__ __forceinline__ void img_store_pk(char* img, int rs, int col, int rt, int h, const unsigned (&o)[8]) {
-#pragma unroll
-    for (int qd = 0; qd < 4; qd++) {
-        u32x2 w = {o[2 * qd], o[2 * qd + 1]};
-        *reinterpret_cast<u32x2*>(img + col * rs + (32 * rt + 8 * qd + 4 * h) * 2) = w;
-    }
+// Two row tiles (2s, 2s+1 of the NTW this wave holds) of one column, 8 values, as one 16-byte store into the [column][channel]
+// image: chunk (4 wr + q) * NTW/2 + s of the row, swizzled.
+__device__ __forceinline__ void img_store8(char* img, int rs, int col, int chunk, const u32x4& w) {
+    *reinterpret_cast<u32x4*>(img + col * rs + swz(col, chunk)) = w;
 }
-__device__ __forceinline__ void img_store(char* img, int rs, int col, int rt, int h, const float (&y)[16]) {
-#pragma unroll
-    for (int qd = 0; qd < 4; qd++)
-        *reinterpret_cast<bf16x4*>(img + col * rs + (32 * rt + 8 * qd + 4 * h) * 2) = pack4(&y[4 * qd]);
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+    unsigned pk;
+    asm(MZ_CVT_PK " %0, %1, %2" : "=v"(pk) : "v"(a), "v"(b));
+    return pk;
 }
-
 
 // relu(LN(v)) of this wave's NR row tiles -> image rows of its own columns.  gb = this LayerNorm's table.
 // gtab != nullptr: the table was copied to LDS under the conv in front (gtab_issue) and is read from there.
-template <int NR, int NW, int NC, bool LDSG = false>
-__device__ __forceinline__ void ln_to_image(Ctx& c, const Col (&k)[NC], const u32x4* gb, const f32x16 (&v)[NR][NC], int nch,
+template <int NR, int NW, int NCL, bool LDSG = false>
+__device__ __forceinline__ void ln_to_image(Ctx& c, const Col (&k)[NCL], const u32x4* gb, const f32x4 (&v)[NR][NCL], int nch,
                                             int rs, const char* gtab = nullptr) {
     char* img = c.smem + c.L.img_off;
-    u32x4 g[NR][NC][4];
-    // the first two row tiles are requested before the statistics round trip, the rest right after it
+    u32x4 g[NR][NCL];
+    // the first four row tiles are requested before the statistics round trip, the rest right after it
     if (!LDSG) {
 #pragma unroll
-        for (int rt = 0; rt < (NR < 2 ? NR : 2); rt++)
+        for (int rt = 0; rt < (NR < 4 ? NR : 4); rt++)
 #pragma unroll
-            for (int ct = 0; ct < NC; ct++) gb_load(gb, c, k[ct], c.wr * NR + rt, g[rt][ct]);
+            for (int ct = 0; ct < NCL; ct++) gb_load(gb, c, k[ct], c.wr * NR + rt, g[rt][ct]);
+        __builtin_amdgcn_sched_barrier(0x38F);  // keep the loads here (everything but VMEM may cross)
     }
-    float mean[NC], rstd[NC];
+    float mean[NCL], rstd[NCL];
     STAMP(c, ST_OTHER);
-    ln_stats<NR, NW, NC, LDSG>(c, k, v, nch, mean, rstd);
+    ln_stats<NR, NW, NCL, LDSG>(c, k, v, nch, mean, rstd);
     STAMP(c, ST_SCOMB);
 #pragma unroll
-    for (int rt = (LDSG ? 0 : 2); rt < NR; rt++)
+    for (int rt = (LDSG ? 0 : 4); rt < NR; rt++)
 #pragma unroll
-        for (int ct = 0; ct < NC; ct++) {
+        for (int ct = 0; ct < NCL; ct++) {
             if (LDSG) gb_load_lds(gtab, c, k[ct], c.wr * NR + rt, g[rt][ct]);
             else gb_load(gb, c, k[ct], c.wr * NR + rt, g[rt][ct]);
         }
 #pragma unroll
-    for (int rt = 0; rt < NR; rt++)
+    for (int s = 0; s < NR / 2; s++)
 #pragma unroll
-        for (int ct = 0; ct < NC; ct++) {
-            unsigned o[8];
-            ln_apply_pk(v[rt][ct], rstd[ct], -mean[ct] * rstd[ct], g[rt][ct], o);   // padded columns: gamma = beta = 0 -> zeros
-            img_store_pk(img, rs, k[ct].col, c.wr * NR + rt, c.h, o);
+        for (int ct = 0; ct < NCL; ct++) {
+            unsigned o0[2], o1[2];
+            const float nmr = -mean[ct] * rstd[ct];
+            ln_apply_pk(v[2 * s][ct], rstd[ct], nmr, g[2 * s][ct], o0);   // padded columns: gamma = beta = 0 -> zeros
+            ln_apply_pk(v[2 * s + 1][ct], rstd[ct], nmr, g[2 * s + 1][ct], o1);
+            img_store8(img, rs, k[ct].col, (4 * c.wr + c.q) * (NR / 2) + s, (u32x4){o0[0], o0[1], o1[0], o1[1]});
         }
     STAMP(c, ST_NORM);
 }
 
-// acc[ro][ct] += conv(image) for this wave's NROW output row tiles (of NROT in the layer) x NC column tiles.
-// Stream order of the layer's fragments: (tap, ks, ro) with natural k.  The first two stages of the stream from
-// here on must already be in flight; after1 / after2 = the two stages that follow this conv's last (0: nothing).
-// LDS reads per MFMA = (NROW + NC) / (NROW * NC): the A fragments are shared by the wave's column tiles.
+// MFMAs of one k-step interleaved with the NRD ds_reads of the next one (sched_group_barrier pattern: the reads are dealt
+// out between the MFMAs instead of standing in a block in front of them, where both waves of a SIMD would issue them
+// while the matrix pipe drains).
+template <int M, int NRD>
+__device__ __forceinline__ void deal_reads() {
+#pragma unroll
+    for (int m = 0; m < M; m++) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        const int nr = (m + 1) * NRD / M - m * NRD / M;
+        if (nr == 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        else if (nr == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        else if (nr == 3) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+        else if (nr >= 4) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+    }
+}
+
+// acc[ro][ct] += conv(image) for this wave's NROW output row tiles (of NROT in the layer) x NCL column tiles.
+// KS = k-steps (32 input channels) per tap.  Stream order of the layer's fragments: (tap, ks, ro), k in image order.
+// The first two stages of the stream from here on must already be in flight; after1 / after2 = the two stages that
+// follow this conv's last (0: nothing).
+// LDS reads per MFMA = (NROW + NCL) / (NROW * NCL): the A fragments are shared by the wave's column tiles.
 struct NoHook {
     __device__ __forceinline__ void operator()() const {}
 };
 // hook: called once, right after the first stage's barrier and DMA issue (every wave has left the LayerNorm in front of
 // this conv by then, and loads requested here do not sit in front of that barrier's vmcnt(0))
 template <class G, int KS, int TAPS, int NROT, int NROW, int RS, class Hook = NoHook>
-__device__ __forceinline__ void conv_lds(Ctx& c, const Col (&k)[G::NC], WRing<G::NW, G::SM>& ring,
-                                         f32x16 (&acc)[NROW][G::NC], int after1, int after2, Hook hook = Hook()) {
-    constexpr int NC = G::NC;
+__device__ __forceinline__ void conv_lds(Ctx& c, const Col (&k)[G::NCL], WRing<G::NW, G::SM>& ring,
+                                         f32x4 (&acc)[NROW][G::NCL], int after1, int after2, Hook hook = Hook()) {
+    constexpr int NCL = G::NCL;
     constexpr int KK = TAPS * KS;
     constexpr int SK = stage_ksteps(KK, NROT, G::SM);
     constexpr int NST = num_stages(KK, NROT, G::SM);
@@ -523,91 +587,100 @@ __device__ __forceinline__ void conv_lds(Ctx& c, const Col (&k)[G::NC], WRing<G:
     const char* slot = nullptr;
     const int frag0 = (c.wr * NROW) * 1024 + c.lane * 16;
     struct Ops {
-        bf16x8 b[NC], a[NROW];
+        opx8 b[NCL], a[NROW];
     };
-    // operands of k-step kk: B from the image (own columns, or the tap's neighbour rows), A from ring slot sl
-    auto load_ops = [&](int kk, const char* sl, Ops& o) {
+    // operands of k-step kk: B from the image (own columns, or the tap's neighbour rows), A from the ring slot
+    auto load_b = [&](int kk, Ops& o) {
         const int t = kk / KS, ks = kk % KS;
 #pragma unroll
-        for (int ct = 0; ct < NC; ct++) {
+        for (int ct = 0; ct < NCL; ct++) {
             const char* row;
+            int v = k[ct].col;
             if (TAPS == 9) {
-                const int d = (t / 3 - 1) * c.Wd + (t % 3 - 1);
-                const int v = k[ct].col + d;
+                v += (t / 3 - 1) * c.Wd + (t % 3 - 1);
                 row = ((k[ct].nbmask >> t) & 1u) ? img + v * RS
-                                                 : zrow + (RS == G::CB * 2 + 16 ? ((v + 16 * ZROWS) & (ZROWS - 1)) * c.L.zstride : 0);
+                                                 : zrow + (RS == G::CB * 2 + 32 ? ((v + 16 * ZROWS) & (ZROWS - 1)) * c.L.zstride : 0);
             } else {
-                row = img + k[ct].col * RS;
+                row = img + v * RS;
             }
-            o.b[ct] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(row + (16 * ks + 8 * c.h) * 2));
+            o.b[ct] = __builtin_bit_cast(opx8, *reinterpret_cast<const u32x4*>(row + 64 * ks + swz(v, c.q)));
         }
+    };
+    auto load_a = [&](int kk, Ops& o) {
 #pragma unroll
         for (int ro = 0; ro < NROW; ro++)
-            o.a[ro] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(sl + ((kk % SK) * NROT + ro) * 1024));
+            o.a[ro] = __builtin_bit_cast(opx8, *reinterpret_cast<const u32x4*>(slot + ((kk % SK) * NROT + ro) * 1024));
     };
-    // Software pipeline: the operands of k-step kk+1 are requested before the MFMAs of kk issue (inside a stage;
-    // a new stage starts with its barrier), so LDS latency hides behind the matrix pipe instead of in front of it.
-    // Measured no better (k_seg 2 % slower): two k-steps ahead with three operand sets, and running the look-ahead
-    // across the stage barriers - the loops are bound by LDS throughput (1.5 ds_read_b128 per MFMA), not latency.
-    Ops ocur, onxt;
+    // Software pipeline: the operands of k-step kk+1 are requested while the MFMAs of kk issue; the B operands across the
+    // stage barriers too (the image does not change inside a conv), the A fragments of a stage's first k-step right behind
+    // its barrier.  LDS latency hides behind the matrix pipe instead of in front of it.
+    Ops o[2];
 #pragma unroll
     for (int kk = 0; kk < KK; kk++) {
         if (kk % SK == 0) {
             STAMP(c, kk == 0 ? ST_OTHER : ST_MMA);
-            slot = ring.acquire() + frag0;
+            slot = (kk == 0 ? ring.acquire(c) : ring.acquire_x(c)) + frag0;
             STAMP(c, ST_ACQ);
             const int j = kk / SK + 2;   // the stage requested now
-            ring.issue(j < NST ? stage_frags(KK, NROT, G::SM, j) : (j == NST ? after1 : after2));
-            if (kk == 0) hook();
-            load_ops(kk, slot, ocur);
+            if (kk == 0) hook();         // in front of the issue: older than the pieces that may stay in flight
+            ring.issue(c, j < NST ? stage_frags(KK, NROT, G::SM, j) : (j == NST ? after1 : after2));
+            if (kk == 0) load_b(0, o[0]);
+            load_a(kk, o[kk & 1]);
         }
-        const bool more = kk + 1 < KK && (kk + 1) % SK != 0;
-        if (more) load_ops(kk + 1, slot, onxt);
-        __builtin_amdgcn_sched_barrier(0);   // the scheduler would otherwise sink these reads below the MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        const bool more = kk + 1 < KK, same = (kk + 1) % SK != 0;
+        if (more) {
+            load_b(kk + 1, o[(kk + 1) & 1]);
+            if (same) load_a(kk + 1, o[(kk + 1) & 1]);
+        }
 #pragma unroll
         for (int ro = 0; ro < NROW; ro++)
 #pragma unroll
-            for (int ct = 0; ct < NC; ct++) acc[ro][ct] = MFMA(ocur.a[ro], ocur.b[ct], acc[ro][ct]);
+            for (int ct = 0; ct < NCL; ct++) acc[ro][ct] = MFMA(o[kk & 1].a[ro], o[kk & 1].b[ct], acc[ro][ct]);
+#if !defined(MZ_X_NODEAL)
+        if (more && same) deal_reads<NROW * NCL, NROW + NCL>();
+        else if (more) deal_reads<NROW * NCL, NCL>();
+#endif
         __builtin_amdgcn_sched_barrier(0);
-        if (more) ocur = onxt;
     }
     STAMP(c, ST_MMA);
 }
 
 // relu(LN(v)) of this wave's NR row tiles kept in registers as MFMA B operands (WR = 1: the wave holds every
-// channel of its columns).  A lane's 16 accumulator rows of row tile rt are the channels 32rt + 8qd + 4h + e; packed
-// in that order they are the B operands of two k-steps whose k index runs k = 8h + j <-> channel
-// 32rt + 16s + 4h + (j & 3) + 8(j >> 2) (s = k-step parity) - the order pack_conv_kperm gives the A fragments.
+// channel of its columns).  A lane's 8 values of the row tiles 2s, 2s+1 are the B operand of k-step s for its column:
+// k index 8q + j <-> channel 16 (2s + (j >> 2)) + 4q + (j & 3) - the order pack_conv_kperm gives the A fragments.
 // No LDS image, no ds_write, no B reads for the 1x1 convs.
-template <int NR, int NW, int NC, bool LDSG = false>
-__device__ __forceinline__ void ln_to_regs(Ctx& c, const Col (&k)[NC], const u32x4* gb, const f32x16 (&v)[NR][NC], int nch,
-                                           u32x4 (&bop)[2 * NR][NC], const char* gtab = nullptr) {
-    u32x4 g[NR][NC][4];
+template <int NR, int NW, int NCL, bool LDSG = false>
+__device__ __forceinline__ void ln_to_regs(Ctx& c, const Col (&k)[NCL], const u32x4* gb, const f32x4 (&v)[NR][NCL], int nch,
+                                           u32x4 (&bop)[NR / 2][NCL], const char* gtab = nullptr) {
+    u32x4 g[NR][NCL];
     if (!LDSG) {
 #pragma unroll
-        for (int rt = 0; rt < (NR < 2 ? NR : 2); rt++)
+        for (int rt = 0; rt < (NR < 4 ? NR : 4); rt++)
 #pragma unroll
-            for (int ct = 0; ct < NC; ct++) gb_load(gb, c, k[ct], rt, g[rt][ct]);
+            for (int ct = 0; ct < NCL; ct++) gb_load(gb, c, k[ct], rt, g[rt][ct]);
+        __builtin_amdgcn_sched_barrier(0x38F);
     }
-    float mean[NC], rstd[NC];
+    float mean[NCL], rstd[NCL];
     STAMP(c, ST_OTHER);
-    ln_stats<NR, NW, NC, LDSG>(c, k, v, nch, mean, rstd);
+    ln_stats<NR, NW, NCL, LDSG>(c, k, v, nch, mean, rstd);
     STAMP(c, ST_SCOMB);
 #pragma unroll
-    for (int rt = (LDSG ? 0 : 2); rt < NR; rt++)
+    for (int rt = (LDSG ? 0 : 4); rt < NR; rt++)
 #pragma unroll
-        for (int ct = 0; ct < NC; ct++) {
+        for (int ct = 0; ct < NCL; ct++) {
             if (LDSG) gb_load_lds(gtab, c, k[ct], rt, g[rt][ct]);
             else gb_load(gb, c, k[ct], rt, g[rt][ct]);
         }
 #pragma unroll
-    for (int rt = 0; rt < NR; rt++)
+    for (int s = 0; s < NR / 2; s++)
 #pragma unroll
-        for (int ct = 0; ct < NC; ct++) {
-            unsigned o[8];
-            ln_apply_pk(v[rt][ct], rstd[ct], -mean[ct] * rstd[ct], g[rt][ct], o);   // padded columns: gamma = beta = 0 -> zeros
-            bop[2 * rt][ct] = (u32x4){o[0], o[1], o[2], o[3]};
-            bop[2 * rt + 1][ct] = (u32x4){o[4], o[5], o[6], o[7]};
+        for (int ct = 0; ct < NCL; ct++) {
+            unsigned o0[2], o1[2];
+            const float nmr = -mean[ct] * rstd[ct];
+            ln_apply_pk(v[2 * s][ct], rstd[ct], nmr, g[2 * s][ct], o0);   // padded columns: gamma = beta = 0 -> zeros
+            ln_apply_pk(v[2 * s + 1][ct], rstd[ct], nmr, g[2 * s + 1][ct], o1);
+            bop[s][ct] = (u32x4){o0[0], o0[1], o1[0], o1[1]};
         }
     STAMP(c, ST_NORM);
 }
@@ -615,128 +688,131 @@ __device__ __forceinline__ void ln_to_regs(Ctx& c, const Col (&k)[NC], const u32
 // acc[ro][ct] += W * bop for a 1x1 conv whose B operands are in registers (KS k-steps, fragments (ks, ro) in k-permuted
 // order); same ring protocol as conv_lds.
 template <class G, int KS, int NROT, class Hook = NoHook>
-__device__ __forceinline__ void conv_regs(Ctx& c, WRing<G::NW, G::SM>& ring, const u32x4 (&bop)[KS][G::NC],
-                                          f32x16 (&acc)[NROT][G::NC], int after1, int after2, Hook hook = Hook()) {
-    constexpr int NC = G::NC;
+__device__ __forceinline__ void conv_regs(Ctx& c, WRing<G::NW, G::SM>& ring, const u32x4 (&bop)[KS][G::NCL],
+                                          f32x4 (&acc)[NROT][G::NCL], int after1, int after2, Hook hook = Hook()) {
+    constexpr int NCL = G::NCL;
     constexpr int SK = stage_ksteps(KS, NROT, G::SM);
     constexpr int NST = num_stages(KS, NROT, G::SM);
     const char* slot = nullptr;
-    auto load_a = [&](int kk, bf16x8(&a)[NROT]) {
+    auto load_a = [&](int kk, opx8(&a)[NROT]) {
 #pragma unroll
         for (int ro = 0; ro < NROT; ro++)
-            a[ro] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(slot + ((kk % SK) * NROT + ro) * 1024));
+            a[ro] = __builtin_bit_cast(opx8, *reinterpret_cast<const u32x4*>(slot + ((kk % SK) * NROT + ro) * 1024));
     };
-    bf16x8 acur[NROT], anxt[NROT];
+    opx8 a[2][NROT];
 #pragma unroll
     for (int kk = 0; kk < KS; kk++) {
         if (kk % SK == 0) {
             STAMP(c, kk == 0 ? ST_OTHER : ST_MMA);
-            slot = ring.acquire() + c.lane * 16;
+#if defined(MZ_X_NOBAR14)
+            slot = ring.acquire_nobar(c) + c.lane * 16;
+#else
+            slot = (kk == 0 ? ring.acquire(c) : ring.acquire_x(c)) + c.lane * 16;
+#endif
             STAMP(c, ST_ACQ);
             const int j = kk / SK + 2;
-            ring.issue(j < NST ? stage_frags(KS, NROT, G::SM, j) : (j == NST ? after1 : after2));
             if (kk == 0) hook();
-            load_a(kk, acur);
+            ring.issue(c, j < NST ? stage_frags(KS, NROT, G::SM, j) : (j == NST ? after1 : after2));
+            load_a(kk, a[kk & 1]);
         }
-        const bool more = kk + 1 < KS && (kk + 1) % SK != 0;
-        if (more) load_a(kk + 1, anxt);
         __builtin_amdgcn_sched_barrier(0);
+        const bool more = kk + 1 < KS && (kk + 1) % SK != 0;
+        if (more) load_a(kk + 1, a[(kk + 1) & 1]);
 #pragma unroll
         for (int ro = 0; ro < NROT; ro++)
 #pragma unroll
-            for (int ct = 0; ct < NC; ct++)
-                acc[ro][ct] = MFMA(acur[ro], __builtin_bit_cast(bf16x8, bop[kk][ct]), acc[ro][ct]);
+            for (int ct = 0; ct < NCL; ct++)
+                acc[ro][ct] = MFMA(a[kk & 1][ro], __builtin_bit_cast(opx8, bop[kk][ct]), acc[ro][ct]);
+#if !defined(MZ_X_NODEAL)
+        if (more) deal_reads<NROT * NCL, NROT>();
+#endif
         __builtin_amdgcn_sched_barrier(0);
-        if (more) {
-#pragma unroll
-            for (int ro = 0; ro < NROT; ro++) acur[ro] = anxt[ro];
-        }
     }
     STAMP(c, ST_MMA);
 }
 
-template <int NR, int NC>
-__device__ __forceinline__ void zero_acc(f32x16 (&a)[NR][NC]) {
+template <int NR, int NCL>
+__device__ __forceinline__ void zero_acc(f32x4 (&a)[NR][NCL]) {
 #pragma unroll
     for (int r = 0; r < NR; r++)
 #pragma unroll
-        for (int ct = 0; ct < NC; ct++)
+        for (int ct = 0; ct < NCL; ct++)
 #pragma unroll
-            for (int i = 0; i < 16; i++) a[r][ct][i] = 0.f;
+            for (int i = 0; i < 4; i++) a[r][ct][i] = 0.f;
 }
 
 // BottleneckResidualBlock: x + c4(relu(LN(c3(relu(LN(c2(relu(LN(c1(relu(LN(x))))))))))))
 // Stage sizes of a block's four convs, and the two stages that open a block.
 template <class G>
 struct BlockStages {
-    static constexpr int KSC = G::C / 16, KSB = G::CB / 16, SM = G::SM;
-    static constexpr int c1(int j) { return stage_frags(KSC, G::NRB, SM, j); }
-    static constexpr int c2(int j) { return stage_frags(9 * KSB, G::NRB, SM, j); }
-    static constexpr int c4(int j) { return stage_frags(KSB, G::NRC, SM, j); }
-    static constexpr int n1 = num_stages(KSC, G::NRB, SM), n4 = num_stages(KSB, G::NRC, SM);
-    static_assert(num_stages(9 * KSB, G::NRB, SM) >= 2, "3x3 convs span at least two stages");
+    static constexpr int KSC = G::C / 32, KSB = G::CB / 32, SM = G::SM;
+    static constexpr int c1(int j) { return stage_frags(KSC, G::NTB, SM, j); }
+    static constexpr int c2(int j) { return stage_frags(9 * KSB, G::NTB, SM, j); }
+    static constexpr int c4(int j) { return stage_frags(KSB, G::NTC, SM, j); }
+    static constexpr int n1 = num_stages(KSC, G::NTB, SM), n4 = num_stages(KSB, G::NTC, SM);
+    static_assert(num_stages(9 * KSB, G::NTB, SM) >= 2, "3x3 convs span at least two stages");
     static constexpr int open0 = c1(0), open1 = n1 > 1 ? c1(1) : c2(0);
 };
 
 // On entry the first two stages of the block are in flight; on exit those of the next block (if has_next).
 template <class G>
-__device__ __forceinline__ void bottleneck(Ctx& c, const Col (&k)[G::NC], WRing<G::NW, G::SM>& ring, const u32x4* gb,
-                                           f32x16 (&X)[G::NRCW][G::NC], bool has_next) {
+__device__ __forceinline__ void bottleneck(Ctx& c, const Col (&k)[G::NCL], WRing<G::NW, G::SM>& ring, const u32x4* gb,
+                                           f32x4 (&X)[G::NTCW][G::NCL], bool has_next) {
     constexpr int C = G::C, CB = G::CB;
     using BS = BlockStages<G>;
     const int nx0 = has_next ? BS::open0 : 0, nx1 = has_next ? BS::open1 : 0;
-    constexpr int RSC = C * 2 + 16, RSB = CB * 2 + 16;
-    constexpr int KSC = C / 16, KSB = CB / 16;
-    const long long e = c.HW + 1;                   // table entries per (rt, qd, h)
+    constexpr int RSC = C * 2 + 32, RSB = CB * 2 + 32;
+    constexpr int KSC = C / 32, KSB = CB / 32;
+    const long long e = c.HW + 1;                   // table entries per channel quad
     const u32x4* gb1 = gb;
-    const u32x4* gb2 = gb1 + G::NRC * 8 * e;
-    const u32x4* gb3 = gb2 + G::NRB * 8 * e;
-    const u32x4* gb4 = gb3 + G::NRB * 8 * e;
-    f32x16 a1[G::NRBW][G::NC];
+    const u32x4* gb2 = gb1 + G::NTC * 4 * e;
+    const u32x4* gb3 = gb2 + G::NTB * 4 * e;
+    const u32x4* gb4 = gb3 + G::NTB * 4 * e;
+    f32x4 a1[G::NTBW][G::NCL];
     // Single-row wave grids: the tables of LN2, LN3, LN4 are copied to LDS under the conv in front of each, behind the
     // bottleneck image (which the register-fed 1x1 convs leave to the 3x3 convs alone).
     constexpr bool LG = G::WR == 1;
     char* gtab = c.smem + c.L.img_off + (G::COLS * RSB + 1023) / 1024 * 1024;
-    const int gbytes = G::NRB * 8 * (int)e * 16;
+    const int gbytes = G::NTB * 4 * (int)e * 16;
     auto cp2 = [&]() { if (LG) gtab_issue<G::NW>(c, gb2, gbytes, gtab); };
     auto cp3 = [&]() { if (LG) gtab_issue<G::NW>(c, gb3, gbytes, gtab); };
     auto cp4 = [&]() { if (LG) gtab_issue<G::NW>(c, gb4, gbytes, gtab); };
 
     // LN1 -> c1 (1x1, C -> CB): B operands from registers when the wave holds all channels, else through the image
     if constexpr (G::WR == 1) {
-        u32x4 bop[KSC][G::NC];
-        ln_to_regs<G::NRC, G::NW, G::NC>(c, k, gb1, X, C, bop);
+        u32x4 bop[KSC][G::NCL];
+        ln_to_regs<G::NTC, G::NW, G::NCL>(c, k, gb1, X, C, bop);
         zero_acc(a1);
-        conv_regs<G, KSC, G::NRB>(c, ring, bop, a1, BS::c2(0), BS::c2(1), cp2);
+        conv_regs<G, KSC, G::NTB>(c, ring, bop, a1, BS::c2(0), BS::c2(1), cp2);
     } else {
-        ln_to_image<G::NRCW, G::NW, G::NC>(c, k, gb1, X, C, RSC);
+        ln_to_image<G::NTCW, G::NW, G::NCL>(c, k, gb1, X, C, RSC);
         zero_acc(a1);
-        conv_lds<G, KSC, 1, G::NRB, G::NRBW, RSC>(c, k, ring, a1, BS::c2(0), BS::c2(1));
+        conv_lds<G, KSC, 1, G::NTB, G::NTBW, RSC>(c, k, ring, a1, BS::c2(0), BS::c2(1));
     }
     // LN2 -> image -> c2 (3x3), LN3 -> image -> c3 (3x3); the image is consumed before a1 is rewritten
 #pragma unroll
     for (int layer = 0; layer < 2; layer++) {
-        ln_to_image<G::NRBW, G::NW, G::NC, LG>(c, k, layer == 0 ? gb2 : gb3, a1, CB, RSB, gtab);
+        ln_to_image<G::NTBW, G::NW, G::NCL, LG>(c, k, layer == 0 ? gb2 : gb3, a1, CB, RSB, gtab);
         zero_acc(a1);
         if (layer == 0)
-            conv_lds<G, KSB, 9, G::NRB, G::NRBW, RSB>(c, k, ring, a1, BS::c2(0), BS::c2(1), cp3);
+            conv_lds<G, KSB, 9, G::NTB, G::NTBW, RSB>(c, k, ring, a1, BS::c2(0), BS::c2(1), cp3);
         else
-            conv_lds<G, KSB, 9, G::NRB, G::NRBW, RSB>(c, k, ring, a1, BS::c4(0), BS::n4 > 1 ? BS::c4(1) : nx0, cp4);
+            conv_lds<G, KSB, 9, G::NTB, G::NTBW, RSB>(c, k, ring, a1, BS::c4(0), BS::n4 > 1 ? BS::c4(1) : nx0, cp4);
     }
     // LN4 -> c4 (1x1, CB -> C) accumulated into X
     if constexpr (G::WR == 1) {
-        u32x4 bop[KSB][G::NC];
-        ln_to_regs<G::NRB, G::NW, G::NC, LG>(c, k, gb4, a1, CB, bop, gtab);
-        conv_regs<G, KSB, G::NRC>(c, ring, bop, X, nx0, nx1);
+        u32x4 bop[KSB][G::NCL];
+        ln_to_regs<G::NTB, G::NW, G::NCL, LG>(c, k, gb4, a1, CB, bop, gtab);
+        conv_regs<G, KSB, G::NTC>(c, ring, bop, X, nx0, nx1);
     } else {
-        ln_to_image<G::NRBW, G::NW, G::NC>(c, k, gb4, a1, CB, RSB);
-        conv_lds<G, KSB, 1, G::NRC, G::NRCW, RSB>(c, k, ring, X, nx0, nx1);
+        ln_to_image<G::NTBW, G::NW, G::NCL>(c, k, gb4, a1, CB, RSB);
+        conv_lds<G, KSB, 1, G::NTC, G::NTCW, RSB>(c, k, ring, X, nx0, nx1);
     }
 }
 
 // ---- shared prologue: per-board meta data and per-lane column info -----------------------------
-template <int IN, int NC>
-__device__ __forceinline__ bool setup(const NetDims& d, const NetIO& io, int NB, Ctx& c, Col (&kk)[NC]) {
+template <int IN, int NCL>
+__device__ __forceinline__ bool setup(const NetDims& d, const NetIO& io, int NB, Ctx& c, Col (&kk)[NCL]) {
     const int tid = threadIdx.x;
     const int g0 = blockIdx.x * NB;
     if (tid < MAXNB) {
@@ -754,9 +830,9 @@ __device__ __forceinline__ bool setup(const NetDims& d, const NetIO& io, int NB,
     for (int b = 0; b < NB; b++) any |= c.meta[2 * MAXNB + b];
     if (!any) return false;
 #pragma unroll
-    for (int ct = 0; ct < NC; ct++) {
+    for (int ct = 0; ct < NCL; ct++) {
     Col& k = kk[ct];
-    const int col = 32 * (NC * c.wc + ct) + c.r;
+    const int col = 16 * (NCL * c.wc + ct) + c.r;
     k.col = col;
     k.valid = col < NB * d.HW;
     k.board = k.valid ? col / d.HW : MAXNB;
@@ -786,79 +862,84 @@ __device__ __forceinline__ void ctx_init(Ctx& c, char* smem, const LdsPlan& L, c
     c.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     c.wc = c.wave % G::WC;
     c.wr = c.wave / G::WC;
-    c.h = c.lane >> 5;
-    c.r = c.lane & 31;
+    c.q = c.lane >> 4;
+    c.r = c.lane & 15;
     c.wpart = reinterpret_cast<float*>(smem + L.stat_off);
     c.parity = 0;
+    c.vm_young = 0;
     c.meta = reinterpret_cast<int*>(smem + L.meta_off);
-#if defined(MZ_STAMPS)
+#if defined(MZ_TL)
+    c.tl_on = false;
+    c.tl_n = 0;
+#elif defined(MZ_STAMPS)
     for (int i = 0; i < 16; i++) c.st_acc[i] = 0;
     c.st_last = __builtin_amdgcn_s_memtime();
 #endif
 }
 
 // X <-> the hidden-state pool (slot index from meta row `which`); this wave's row tiles.  On this path a slot is
-// laid out [C/4][HW][4] fp32 (channel quads interleaved): a lane's four consecutive accumulator registers (channels
-// 32rt + 8qd + 4h + 0..3 of its cell) are one 16-byte access and a wave's accesses are contiguous 512-byte runs -
-// 16 instead of 64 memory instructions per lane.  mz_read_hidden un-permutes (api.cpp).
-template <int NR, int NC>
-__device__ __forceinline__ void x_load(Ctx& c, const Col (&kk)[NC], const float* pool, int which, int C, f32x16 (&X)[NR][NC]) {
+// laid out [C/4][HW][4] fp32 (channel quads interleaved): a lane's four accumulator registers of a tile (channels
+// 16t + 4q + 0..3 of its cell) are one 16-byte access and 16 lanes' accesses a contiguous 256-byte run.
+// mz_read_hidden un-permutes (api.cpp).
+template <int NR, int NCL>
+__device__ __forceinline__ void x_load(Ctx& c, const Col (&kk)[NCL], const float* pool, int which, int C, f32x4 (&X)[NR][NCL]) {
     // unconditional loads (dead columns read slot meta[..][0], which is always a valid slot) + select:
     // a per-load branch would serialise dependent round trips
 #pragma unroll
-    for (int ct = 0; ct < NC; ct++) {
+    for (int ct = 0; ct < NCL; ct++) {
         const Col& k = kk[ct];
         const int bd = k.valid ? k.board : 0;
-        const float* src = pool + (long long)c.meta[which * MAXNB + bd] * C * c.HW + (k.p + c.h * c.HW) * 4;
+        const float* src = pool + (long long)c.meta[which * MAXNB + bd] * C * c.HW + (k.p + c.q * c.HW) * 4;
         int hw = c.HW;
         asm volatile("" : "+s"(hw));   // opaque per call: keeps the compiler from holding (and spilling) the row offsets
         const bool keep = k.live;
 #pragma unroll
-        for (int rt = 0; rt < NR; rt++)
+        for (int rt = 0; rt < NR; rt++) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * (c.wr * NR + rt) * hw * 4);
 #pragma unroll
-            for (int qd = 0; qd < 4; qd++) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(src + (8 * (c.wr * NR + rt) + 2 * qd) * hw * 4);
-#pragma unroll
-                for (int e = 0; e < 4; e++) X[rt][ct][4 * qd + e] = keep ? v[e] : 0.f;  // select: dead slots may hold NaN bit patterns
-            }
+            for (int e = 0; e < 4; e++) X[rt][ct][e] = keep ? v[e] : 0.f;  // select: dead slots may hold NaN bit patterns
+        }
     }
 }
-template <int NR, int NC>
-__device__ __forceinline__ void x_store(Ctx& c, const Col (&kk)[NC], float* pool, int C, const f32x16 (&X)[NR][NC]) {
+template <int NR, int NCL>
+__device__ __forceinline__ void x_store(Ctx& c, const Col (&kk)[NCL], float* pool, int C, const f32x4 (&X)[NR][NCL]) {
 #pragma unroll
-    for (int ct = 0; ct < NC; ct++) {
+    for (int ct = 0; ct < NCL; ct++) {
         const Col& k = kk[ct];
         if (!k.live) continue;
-        float* dst = pool + (long long)c.meta[MAXNB + k.board] * C * c.HW + (k.p + c.h * c.HW) * 4;
+        float* dst = pool + (long long)c.meta[MAXNB + k.board] * C * c.HW + (k.p + c.q * c.HW) * 4;
         int hw = c.HW;
         asm volatile("" : "+s"(hw));
 #pragma unroll
-        for (int rt = 0; rt < NR; rt++)
-#pragma unroll
-            for (int qd = 0; qd < 4; qd++)
-                *reinterpret_cast<f32x4*>(dst + (8 * (c.wr * NR + rt) + 2 * qd) * hw * 4) =
-                    (f32x4){X[rt][ct][4 * qd], X[rt][ct][4 * qd + 1], X[rt][ct][4 * qd + 2], X[rt][ct][4 * qd + 3]};
+        for (int rt = 0; rt < NR; rt++) *reinterpret_cast<f32x4*>(dst + 4 * (c.wr * NR + rt) * hw * 4) = X[rt][ct];
     }
 }
 
 // ---- bottleneck blocks b0..b1-1, then the X store or [rescale + hidden-state store + head convs] ----------
 template <class G, int OUT>
-__device__ __forceinline__ void seg_rest(Ctx& c, const Col (&k)[G::NC], const NetDims& d, const TowerDev& tw, const HeadDev& hd,
+__device__ __forceinline__ void seg_rest(Ctx& c, const Col (&k)[G::NCL], const NetDims& d, const TowerDev& tw, const HeadDev& hd,
                                          const NetIO& io, const LdsPlan& L, char* smem, WRing<G::NW, G::SM>& ring,
-                                         f32x16 (&X)[G::NRCW][G::NC], int NB, int b0, int b1) {
-    constexpr int C = G::C, NRCW = G::NRCW, NC = G::NC;
+                                         f32x4 (&X)[G::NTCW][G::NCL], int NB, int b0, int b1) {
+    constexpr int C = G::C, NTCW = G::NTCW, NCL = G::NCL;
     const int HW = d.HW;
     const int g0 = blockIdx.x * NB;
     {
         const u32x4* gbase = tw.gb;
-        for (int blk = b0; blk < b1; blk++)
+        for (int blk = b0; blk < b1; blk++) {
+#if defined(MZ_TL)
+            c.tl_on = blockIdx.x == 0 && blk == 3;
+#endif
             bottleneck<G>(c, k, ring, gbase + tw.gboff[blk], X, blk + 1 < b1);
+#if defined(MZ_TL)
+            c.tl_on = false;
+#endif
+        }
     }
     if (OUT == OUT_REGS) return;
 
     if (OUT == OUT_X) {
         STAMP(c, ST_OTHER);
-        x_store<NRCW, NC>(c, k, io.pool, C, X);
+        x_store<NTCW, NCL>(c, k, io.pool, C, X);
         STAMP(c, ST_XSTORE);
         STAMP_PRINT(c, "seg");
         return;
@@ -866,15 +947,15 @@ __device__ __forceinline__ void seg_rest(Ctx& c, const Col (&k)[G::NC], const Ne
     STAMP(c, ST_OTHER);
     // ---------------- RescaleBlockExt + hidden-state store ----------------
     {
-        float mn[NC], mx[NC];
+        float mn[NCL], mx[NCL];
 #pragma unroll
-        for (int ct = 0; ct < NC; ct++) {
+        for (int ct = 0; ct < NCL; ct++) {
             mn[ct] = INFINITY;
             mx[ct] = -INFINITY;
 #pragma unroll
-            for (int rt = 0; rt < NRCW; rt++)
+            for (int rt = 0; rt < NTCW; rt++)
 #pragma unroll
-                for (int i = 0; i < 16; i++) {
+                for (int i = 0; i < 4; i++) {
                     mn[ct] = fminf(mn[ct], X[rt][ct][i]);
                     mx[ct] = fmaxf(mx[ct], X[rt][ct][i]);
                 }
@@ -883,60 +964,58 @@ __device__ __forceinline__ void seg_rest(Ctx& c, const Col (&k)[G::NC], const Ne
                 mx[ct] = -INFINITY;
             }
         }
-        board_reduce<1, G::NW, NC>(c, k, mn, mx, 0.f);
+        board_reduce<1, G::NW, NCL>(c, k, mn, mx, 0.f);
 #pragma unroll
-        for (int ct = 0; ct < NC; ct++) {
+        for (int ct = 0; ct < NCL; ct++) {
             const float dd = fmaxf(mx[ct] - mn[ct], 1e-5f);
 #pragma unroll
-            for (int rt = 0; rt < NRCW; rt++)
+            for (int rt = 0; rt < NTCW; rt++)
 #pragma unroll
-                for (int i = 0; i < 16; i++) X[rt][ct][i] = (X[rt][ct][i] - mn[ct]) / dd;
+                for (int i = 0; i < 4; i++) X[rt][ct][i] = (X[rt][ct][i] - mn[ct]) / dd;
         }
         STAMP(c, ST_RESCALE);
-        x_store<NRCW, NC>(c, k, io.pool, C, X);
+        x_store<NTCW, NCL>(c, k, io.pool, C, X);
         STAMP(c, ST_XSTORE);
     }
     // ---------------- the 1x1 convs that open the prediction heads (C -> policy 0, policy 1, value) -------------
     // Taken here off the registers, so that k_heads reads 3 values per cell instead of the whole hidden state again.
-    // A lane holds 16 * NRCW channels of its cell: per-lane partial dot products -> LDS (the image is dead) -> the
-    // 2 * WR partials of a cell are summed in a fixed order by the lane (wr = 0, h = 0) of that column.
+    // A lane holds 4 * NTCW channels of its cell: per-lane partial dot products -> LDS (the image is dead) -> the
+    // 4 * WR partials of a cell are summed in a fixed order by the lane (wr = 0, q = 0) of that column.
     {
-        float* hpart = reinterpret_cast<float*>(smem + L.img_off);   // [2 * WR][3][COLS]
-        float part[NC][3];
+        float* hpart = reinterpret_cast<float*>(smem + L.img_off);   // [4 * WR][3][COLS]
+        float part[NCL][3];
 #pragma unroll
-        for (int ct = 0; ct < NC; ct++)
+        for (int ct = 0; ct < NCL; ct++)
 #pragma unroll
             for (int o = 0; o < 3; o++) part[ct][o] = 0.f;
 #pragma unroll
-        for (int rt = 0; rt < NRCW; rt++) {
-            f32x4 w[3][4];
+        for (int rt = 0; rt < NTCW; rt++) {
+            f32x4 w[3];
 #pragma unroll
             for (int o = 0; o < 3; o++)
+                w[o] = *reinterpret_cast<const f32x4*>(hd.hconv + o * C + 16 * (c.wr * NTCW + rt) + 4 * c.q);
 #pragma unroll
-                for (int qd = 0; qd < 4; qd++)
-                    w[o][qd] = *reinterpret_cast<const f32x4*>(hd.hconv + o * C + 32 * (c.wr * NRCW + rt) + 8 * qd + 4 * c.h);
-#pragma unroll
-            for (int ct = 0; ct < NC; ct++)
+            for (int ct = 0; ct < NCL; ct++)
 #pragma unroll
                 for (int o = 0; o < 3; o++)
 #pragma unroll
-                    for (int i = 0; i < 16; i++) part[ct][o] = fmaf(X[rt][ct][i], w[o][i >> 2][i & 3], part[ct][o]);
+                    for (int i = 0; i < 4; i++) part[ct][o] = fmaf(X[rt][ct][i], w[o][i], part[ct][o]);
         }
 #pragma unroll
-        for (int ct = 0; ct < NC; ct++)
+        for (int ct = 0; ct < NCL; ct++)
 #pragma unroll
-            for (int o = 0; o < 3; o++) hpart[((c.wr * 2 + c.h) * 3 + o) * G::COLS + k[ct].col] = part[ct][o];
+            for (int o = 0; o < 3; o++) hpart[((c.wr * 4 + c.q) * 3 + o) * G::COLS + k[ct].col] = part[ct][o];
         lds_barrier();
-        if (c.wr == 0 && c.h == 0) {
+        if (c.wr == 0 && c.q == 0) {
 #pragma unroll
-            for (int ct = 0; ct < NC; ct++) {
+            for (int ct = 0; ct < NCL; ct++) {
                 if (!k[ct].live) continue;
                 float* dst = hd.hfeat + ((long long)(io.g_base + g0 + k[ct].board) * 3) * HW + k[ct].p;
 #pragma unroll
                 for (int o = 0; o < 3; o++) {
                     float sum = 0.f;
 #pragma unroll
-                    for (int j = 0; j < 2 * G::WR; j++) sum += hpart[(j * 3 + o) * G::COLS + k[ct].col];
+                    for (int j = 0; j < 4 * G::WR; j++) sum += hpart[(j * 3 + o) * G::COLS + k[ct].col];
                     dst[o * HW] = sum;
                 }
             }
@@ -945,18 +1024,17 @@ __device__ __forceinline__ void seg_rest(Ctx& c, const Col (&k)[G::NC], const Ne
     STAMP_PRINT(c, "seg+rescale");
 }
 
-// ---- [conv0] + bottleneck blocks b0..b1-1 + [rescale, heads] -----------------------------------
 // ---- front of a tower launch: the ring's first two stages, then X from the pool (IN_X) or the input image + conv0 ----
 template <class G, int IN>
-__device__ __forceinline__ void seg_front(Ctx& c, const Col (&k)[G::NC], const NetDims& d, const TowerDev& tw, const NetIO& io,
-                                          const LdsPlan& L, char* smem, WRing<G::NW, G::SM>& ring, f32x16 (&X)[G::NRCW][G::NC],
+__device__ __forceinline__ void seg_front(Ctx& c, const Col (&k)[G::NCL], const NetDims& d, const TowerDev& tw, const NetIO& io,
+                                          const LdsPlan& L, char* smem, WRing<G::NW, G::SM>& ring, f32x4 (&X)[G::NTCW][G::NCL],
                                           int NB, int b0, int b1) {
-    constexpr int C = G::C, NRCW = G::NRCW, NC = G::NC;
-    // input channels of conv0 on the matrix cores, padded to 16: the observation planes, or the C channels of the parent
+    constexpr int C = G::C, NTCW = G::NTCW, NCL = G::NCL;
+    // input channels of conv0 on the matrix cores, padded to 32: the observation planes, or the C channels of the parent
     // state - the dynamics net's one-hot action planes are added afterwards (below)
     constexpr int CIN0 = IN == IN_OBS ? 32 : C;
-    constexpr int KS0 = CIN0 / 16;
-    constexpr int RS0 = CIN0 * 2 + 16;
+    constexpr int KS0 = CIN0 / 32;
+    constexpr int RS0 = CIN0 * 2 + 32;
     using BS = BlockStages<G>;
     const int HW = d.HW;
     const int g0 = blockIdx.x * NB;
@@ -965,72 +1043,69 @@ __device__ __forceinline__ void seg_front(Ctx& c, const Col (&k)[G::NC], const N
     if (IN == IN_X) {
         ring.init(tw.stream + (long long)tw.foff[b0] * 64, smem + L.ring_off, c.wave, c.lane);
         if (b0 < b1) {
-            ring.issue(BS::open0);
-            ring.issue(BS::open1);
+            ring.issue(c, BS::open0);
+            ring.issue(c, BS::open1);
         }
-        x_load<NRCW, NC>(c, k, io.pool, 1, C, X);
+        x_load<NTCW, NCL>(c, k, io.pool, 1, C, X);
         STAMP(c, ST_XLOAD);
     } else {
         ring.init(tw.stream, smem + L.ring_off, c.wave, c.lane);
-        static_assert(num_stages(9 * KS0, G::NRC, G::SM) >= 2, "conv0 spans at least two stages");
-        ring.issue(stage_frags(9 * KS0, G::NRC, G::SM, 0));
-        ring.issue(stage_frags(9 * KS0, G::NRC, G::SM, 1));
+        static_assert(num_stages(9 * KS0, G::NTC, G::SM) >= 2, "conv0 spans at least two stages");
+        ring.issue(c, stage_frags(9 * KS0, G::NTC, G::SM, 0));
+        ring.issue(c, stage_frags(9 * KS0, G::NTC, G::SM, 1));
         // ---------------- input image + conv0 ----------------
         if (IN == IN_OBS) {
+            // observation planes in natural channel order: lane (r, q) writes channels 8q .. 8q+7 of its columns (chunk q)
             zero_acc(X);
             if (c.wr == 0) {
 #pragma unroll
-                for (int ct = 0; ct < NC; ct++) {
+                for (int ct = 0; ct < NCL; ct++) {
                     const int g = g0 + (k[ct].valid ? k[ct].board : 0);
-                    float y[16];
+                    float y[8];
 #pragma unroll
-                    for (int i = 0; i < 16; i++) {
-                        const int ch = 16 * c.h + i;
+                    for (int i = 0; i < 8; i++) {
+                        const int ch = 8 * c.q + i;
                         y[i] = (k[ct].live && ch < d.O) ? io.obs[((long long)g * d.O + ch) * HW + k[ct].p] : 0.f;
                     }
-                    *reinterpret_cast<bf16x8*>(img + k[ct].col * RS0 + (16 * c.h) * 2) = pack8(&y[0]);
-                    *reinterpret_cast<bf16x8*>(img + k[ct].col * RS0 + (16 * c.h + 8) * 2) = pack8(&y[8]);
+                    img_store8(img, RS0, k[ct].col, c.q, (u32x4){pack2(y[0], y[1]), pack2(y[2], y[3]), pack2(y[4], y[5]), pack2(y[6], y[7])});
                 }
             }
         } else {
-            x_load<NRCW, NC>(c, k, io.pool, 0, C, X);   // StartResidualBlock: X starts as the parent state s
+            x_load<NTCW, NCL>(c, k, io.pool, 0, C, X);   // StartResidualBlock: X starts as the parent state s
 #pragma unroll
-            for (int ct = 0; ct < NC; ct++) {
+            for (int ct = 0; ct < NCL; ct++) {
 #pragma unroll
-                for (int rt = 0; rt < NRCW; rt++) {
-                    float y[16];
-#pragma unroll
-                    for (int i = 0; i < 16; i++) y[i] = X[rt][ct][i];
-                    img_store(img, RS0, k[ct].col, c.wr * NRCW + rt, c.h, y);
+                for (int s = 0; s < NTCW / 2; s++) {
+                    const f32x4 &u = X[2 * s][ct], &w = X[2 * s + 1][ct];
+                    img_store8(img, RS0, k[ct].col, (4 * c.wr + c.q) * (NTCW / 2) + s,
+                               (u32x4){pack2(u[0], u[1]), pack2(u[2], u[3]), pack2(w[0], w[1]), pack2(w[2], w[3])});
                 }
             }
         }
         c.L.img_off = L.img0_off;   // conv0 reads its own image; everything behind it the block images at img_off
-        conv_lds<G, KS0, 9, G::NRC, NRCW, RS0>(c, k, ring, X, b0 < b1 ? BS::open0 : 0, b0 < b1 ? BS::open1 : 0);
+        conv_lds<G, KS0, 9, G::NTC, NTCW, RS0>(c, k, ring, X, b0 < b1 ? BS::open0 : 0, b0 < b1 ? BS::open1 : 0);
         c.L.img_off = L.img_off;
         if (IN == IN_HIDDEN) {
             // ConcatInputsBlock + conv0 on the action planes: plane pl is one-hot at cell q (action cell = pl * HW + q, -1 =
             // none), so its share of conv0 is W[o][C + pl][t] at the one cell p with p + d(t) = q, per tap: a rank-1 update
-            // in exact fp32 instead of a ninth k-step per tap on the matrix cores (11 % of conv0's MFMAs and weight bytes).
+            // in exact fp32 instead of another k-step per tap on the matrix cores.
 #pragma unroll
-            for (int ct = 0; ct < NC; ct++) {
+            for (int ct = 0; ct < NCL; ct++) {
                 const int cell = c.meta[3 * MAXNB + (k[ct].valid ? k[ct].board : 0)];
                 if (k[ct].live && cell >= 0) {
-                    const int pl = cell / HW, q = cell - pl * HW;
+                    const int pl = cell / HW, qc = cell - pl * HW;
                     int tstar = -1;
 #pragma unroll
                     for (int t = 0; t < 9; t++)
-                        if (((k[ct].nbmask >> t) & 1u) && k[ct].p + (t / 3 - 1) * c.Wd + (t % 3 - 1) == q) tstar = t;
+                        if (((k[ct].nbmask >> t) & 1u) && k[ct].p + (t / 3 - 1) * c.Wd + (t % 3 - 1) == qc) tstar = t;
                     if (tstar >= 0 && pl < d.a) {
                         const float* wa = tw.wact + ((size_t)pl * 9 + tstar) * C;
 #pragma unroll
-                        for (int rt = 0; rt < NRCW; rt++)
+                        for (int rt = 0; rt < NTCW; rt++) {
+                            const f32x4 w = *reinterpret_cast<const f32x4*>(wa + 16 * (c.wr * NTCW + rt) + 4 * c.q);
 #pragma unroll
-                            for (int qd = 0; qd < 4; qd++) {
-                                const f32x4 w = *reinterpret_cast<const f32x4*>(wa + 32 * (c.wr * NRCW + rt) + 8 * qd + 4 * c.h);
-#pragma unroll
-                                for (int e = 0; e < 4; e++) X[rt][ct][4 * qd + e] += w[e];
-                            }
+                            for (int e = 0; e < 4; e++) X[rt][ct][e] += w[e];
+                        }
                     }
                 }
             }
@@ -1043,13 +1118,13 @@ template <class G, int IN, int OUT>
 __global__ __launch_bounds__(G::NT, G::WPE) void k_seg(NetDims d, TowerDev tw, HeadDev hd, NetIO io, LdsPlan L, int NB, int b0,
                                             int b1) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NRCW = G::NRCW, NC = G::NC;
+    constexpr int NTCW = G::NTCW, NCL = G::NCL;
     Ctx c;
     ctx_init<G>(c, smem, L, d, NB);
-    Col k[NC];
-    if (!setup<IN, NC>(d, io, NB, c, k)) return;
+    Col k[NCL];
+    if (!setup<IN, NCL>(d, io, NB, c, k)) return;
     WRing<G::NW, G::SM> ring;
-    f32x16 X[NRCW][NC];
+    f32x4 X[NTCW][NCL];
     seg_front<G, IN>(c, k, d, tw, io, L, smem, ring, X, NB, b0, b1);
     seg_rest<G, OUT>(c, k, d, tw, hd, io, L, smem, ring, X, NB, b0, b1);
 }
@@ -1200,26 +1275,28 @@ size_t heads_lds_bytes(const NetDims& d) {
     return (size_t)HS * (3 * HPMAX + d.A + d.C + n1 * d.A + n2 * d.C) * 4;
 }
 
+
 // ---- BroadcastResidualBlock: x + c2(relu(LN(bcast(relu(LN(c1(relu(LN(x))))))))) ------------------
 // LDS: [image, C channels][region 2]; region 2 is the weight ring while c1 and c2 run and the
 // transposed image TB[channel][board*KP + cell] while the broadcast linear runs.
-// KSB = k-steps of the broadcast linear (cells padded to 16*KSB); its weight fragments stay in registers.
+// KSB = k-steps (32 cells) of the broadcast linear (cells padded to KP = 32*KSB; QT = 2*KSB output tiles of 16 cells); its
+// weight fragments stay in registers.
 // Body of the broadcast block: takes X from the destination slots (XREGS: from the registers of the blocks in front of
-// it in the same kernel, parking it in the destination slots meanwhile), leaves x + block(x) in X.  nx0 / nx1 = the two
+// it in the same kernel), leaves x + block(x) in X.  nx0 / nx1 = the two
 // ring stages that follow the block's last conv (the next bottleneck block's opening stages when the kernel goes on).
 template <class G, int KSB, bool XREGS = false>
-__device__ __forceinline__ void bcast_body(Ctx& c, const Col (&k)[G::NC], const TowerDev& tw, const NetIO& io, const LdsPlan& L,
-                                           char* smem, WRing<G::NW, G::SM>& ring, f32x16 (&X)[G::NRCW][G::NC], int NB, int blk,
+__device__ __forceinline__ void bcast_body(Ctx& c, const Col (&k)[G::NCL], const TowerDev& tw, const NetIO& io, const LdsPlan& L,
+                                           char* smem, WRing<G::NW, G::SM>& ring, f32x4 (&X)[G::NTCW][G::NCL], int NB, int blk,
                                            int nx0, int nx1) {
-    constexpr int C = G::C, NRC = G::NRC, NRCW = G::NRCW, NC = G::NC;
-    constexpr int QT = (KSB + 1) / 2, KP = 16 * KSB;
-    constexpr int RS = C * 2 + 16;
-    constexpr int KSC = C / 16;
-    constexpr int FS0 = stage_frags(KSC, NRC, G::SM, 0), FS1 = stage_frags(KSC, NRC, G::SM, 1);
+    constexpr int C = G::C, NTC = G::NTC, NTCW = G::NTCW, NCL = G::NCL;
+    constexpr int QT = 2 * KSB, KP = 32 * KSB;
+    constexpr int RS = C * 2 + 32;
+    constexpr int KSC = C / 32;
+    constexpr int FS0 = stage_frags(KSC, NTC, G::SM, 0), FS1 = stage_frags(KSC, NTC, G::SM, 1);
     const long long e = c.HW + 1;
     const u32x4* gb1 = tw.gb + tw.gboff[blk];
-    const u32x4* gb2 = gb1 + NRC * 8 * e;
-    const u32x4* gb3 = gb2 + NRC * 8 * e;
+    const u32x4* gb2 = gb1 + NTC * 4 * e;
+    const u32x4* gb3 = gb2 + NTC * 4 * e;
     const u32x4* wbf = tw.wbf + tw.wboff[blk];
     const float* bb = tw.bb + tw.bboff[blk];
     const int TBS = L.tbs;
@@ -1227,25 +1304,26 @@ __device__ __forceinline__ void bcast_body(Ctx& c, const Col (&k)[G::NC], const 
     char* img = smem + L.img_off;
     if (XREGS) lds_barrier();   // every wave has left the ring slots of the blocks in front before they are refilled
     ring.init(tw.stream + (long long)tw.foff[blk] * 64, smem + L.ring_off, c.wave, c.lane);
-    ring.issue(FS0);
-    ring.issue(FS1);
-    if (!XREGS) x_load<NRCW, NC>(c, k, io.pool, 1, C, X);   // XREGS: X simply stays in its registers through the block
+    ring.issue(c, FS0);
+    ring.issue(c, FS1);
+    if (!XREGS) x_load<NTCW, NCL>(c, k, io.pool, 1, C, X);   // XREGS: X simply stays in its registers through the block
     {
         // LN1 -> image -> c1 (1x1, C -> C); this wave's share of the output rows stays in registers
-        f32x16 a[NRCW][NC];
-        ln_to_image<NRCW, G::NW, NC>(c, k, gb1, X, C, RS);
+        f32x4 a[NTCW][NCL];
+        ln_to_image<NTCW, G::NW, NCL>(c, k, gb1, X, C, RS);
         zero_acc(a);
-        conv_lds<G, KSC, 1, NRC, NRCW, RS>(c, k, ring, a, 0, 0);
+        conv_lds<G, KSC, 1, NTC, NTCW, RS>(c, k, ring, a, 0, 0);
         STAMP(c, ST_OTHER);
-        // LN2 + ReLU -> bf16 -> transposed image TB (the statistics barrier proves that every wave has
+        // LN2 + ReLU -> 16-bit -> transposed image TB (the statistics barrier proves that every wave has
         // finished c1, so the ring under TB is dead)
-        u32x4 g[NC][NRCW][4];   // requested before the statistics round trip
+        u32x4 g[NTCW][NCL];   // requested before the statistics round trip
 #pragma unroll
-        for (int ct = 0; ct < NC; ct++)
+        for (int rt = 0; rt < NTCW; rt++)
 #pragma unroll
-            for (int rt = 0; rt < NRCW; rt++) gb_load(gb2, c, k[ct], c.wr * NRCW + rt, g[ct][rt]);
-        float mean[NC], rstd[NC];
-        ln_stats<NRCW, G::NW, NC>(c, k, a, C, mean, rstd);
+            for (int ct = 0; ct < NCL; ct++) gb_load(gb2, c, k[ct], c.wr * NTCW + rt, g[rt][ct]);
+        __builtin_amdgcn_sched_barrier(0x38F);
+        float mean[NCL], rstd[NCL];
+        ln_stats<NTCW, G::NW, NCL>(c, k, a, C, mean, rstd);
         for (int i = threadIdx.x; i < C * NB * (KP - c.HW); i += G::NT) {  // zero the K padding of every board
             const int padw = KP - c.HW;
             const int ch = i / (NB * padw), rem = i - ch * (NB * padw);
@@ -1253,22 +1331,23 @@ __device__ __forceinline__ void bcast_body(Ctx& c, const Col (&k)[G::NC], const 
             *reinterpret_cast<op_t*>(tb + ch * TBS + (bd * KP + c.HW + pp) * 2) = (op_t)0.f;
         }
 #pragma unroll
-        for (int ct = 0; ct < NC; ct++)
+        for (int ct = 0; ct < NCL; ct++)
 #pragma unroll
-            for (int rt = 0; rt < NRCW; rt++) {
-                float y[16];
-                ln_apply(a[rt][ct], mean[ct], rstd[ct], g[ct][rt], y);
+            for (int rt = 0; rt < NTCW; rt++) {
+                float y[4];
+                ln_apply(a[rt][ct], mean[ct], rstd[ct], g[rt][ct], y);
                 if (k[ct].valid) {
                     const int cbase = k[ct].board * KP + k[ct].p;
 #pragma unroll
-                    for (int i = 0; i < 16; i++) {
-                        const int ch = 32 * (c.wr * NRCW + rt) + (i & 3) + 8 * (i >> 2) + 4 * c.h;
+                    for (int i = 0; i < 4; i++) {
+                        const int ch = 16 * (c.wr * NTCW + rt) + 4 * c.q + i;
                         *reinterpret_cast<op_t*>(tb + ch * TBS + cbase * 2) = (op_t)y[i];
                     }
                 }
             }
     }
-    // broadcast-linear B fragments and bias (requested here, once the c1 tiles are dead): lane (q = 32qt + r, h) holds Wb[q][16ks + 8h + j]
+    // broadcast-linear B fragments and bias (requested here, once the c1 tiles are dead): lane (r, q) holds
+    // Wb[cell 16qt + r][32ks + 8q + j]
     u32x4 wreg[KSB][QT];
     float bias[QT];
 #pragma unroll
@@ -1276,62 +1355,58 @@ __device__ __forceinline__ void bcast_body(Ctx& c, const Col (&k)[G::NC], const 
 #pragma unroll
         for (int qt = 0; qt < QT; qt++) wreg[ks][qt] = wbf[(ks * QT + qt) * 64 + c.lane];
 #pragma unroll
-    for (int qt = 0; qt < QT; qt++) bias[qt] = bb[32 * qt + c.r];
+    for (int qt = 0; qt < QT; qt++) bias[qt] = bb[16 * qt + c.r];
     __builtin_amdgcn_sched_barrier(0);
     lds_barrier();
     STAMP(c, ST_HCONV);   // (diagnostic slots reused: hconv = LN2 + transpose, hln = pass 0, hfc = statistics)
-    // BroadcastBlock: out[ch][q] = sum_p in[ch][p] * Wb[q][p] + b[q], per board.  Work items (board, row tile)
-    // are dealt round-robin to the waves; an item covers all QT q tiles, one after the other.
-    // Pass 0 accumulates the LN3 statistics, pass 1 recomputes (36 MFMAs, cheaper than holding the tiles) and
+    // BroadcastBlock: out[ch][q] = sum_p in[ch][p] * Wb[q][p] + b[q], per board.  Work items (board, row tile of 16
+    // channels) are dealt round-robin to the waves; an item covers all QT q tiles, one after the other.
+    // Pass 0 accumulates the LN3 statistics, pass 1 recomputes (cheaper than holding the tiles) and
     // writes relu(LN3(.)) to the image; its gamma/beta loads are requested before the recompute.
-    float* ipart = c.wpart + 2 * MAXNB * G::NW * 2;   // [items][2]
-    float* bstat = ipart + 2 * 256;                   // [MAXNB][2]
-    const int nitems = NB * NRC;
+    float* ipart = c.wpart + 4 * NB * G::NW;   // [items][2]
+    float* bstat = ipart + 2 * NB * NTC;       // [NB][2]
+    const int nitems = NB * NTC;
     // separate launch: the residual stream for c2 is requested here (it was not held in registers through c1 and the
     // transpose), so its round trip runs under the two passes
-    if (!XREGS) x_load<NRCW, NC>(c, k, io.pool, 1, C, X);
-    // gamma/beta of LN3 for (row tile rtw, cells q): 4 x 16-byte loads, requested one (item, q tile) ahead in pass 1
-    auto g3_load = [&](int it, int qt, u32x4(&g)[4]) {
+    if (!XREGS) x_load<NTCW, NCL>(c, k, io.pool, 1, C, X);
+    // gamma/beta of LN3 for (row tile rtw, cell q): one 16-byte load, requested one (item, q tile) ahead in pass 1
+    auto g3_load = [&](int it, int qt, u32x4& g) {
         if (it >= nitems) return;
-        const int rtw = it % NRC;
-        const int q = 32 * qt + c.r;
-        const unsigned stride = (unsigned)(c.HW + 1) * 32u;
-        const unsigned off = (unsigned)(c.h * (c.HW + 1) + (q < c.HW ? q : c.HW)) * 16u + (unsigned)(rtw * 4) * stride;
-#pragma unroll
-        for (int qd = 0; qd < 4; qd++)
-            g[qd] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(gb3) + off + qd * stride);
+        const int rtw = it % NTC;
+        const int qc = 16 * qt + c.r;
+        const unsigned off = (unsigned)((4 * rtw + c.q) * (c.HW + 1) + (qc < c.HW ? qc : c.HW)) * 16u;
+        g = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(gb3) + off);
         __builtin_amdgcn_sched_barrier(0x38F);
     };
     for (int pass = 0; pass < 2; pass++) {
-        u32x4 gn[4];
+        u32x4 gn = {0, 0, 0, 0};
         if (pass == 1) g3_load(c.wave, 0, gn);
         for (int it = c.wave; it < nitems; it += G::NW) {
-            const int bd = it / NRC, rtw = it - bd * NRC;
-            const char* arow = tb + (32 * rtw + c.r) * TBS + (bd * KP + 8 * c.h) * 2;
+            const int bd = it / NTC, rtw = it - bd * NTC;
+            const char* arow = tb + (16 * rtw + c.r) * TBS + (bd * KP + 8 * c.q) * 2;
+            // image position of the channels 16 rtw + 4q + 0..3 (the order ln_to_image writes): 8 bytes
+            const int wrt = rtw / NTCW, rh = rtw - wrt * NTCW;
+            const int chunk = (4 * wrt + c.q) * (NTCW / 2) + (rh >> 1), half8 = (rh & 1) * 8;
             float ps = 0.f, pq = 0.f;
 #pragma unroll
             for (int qt = 0; qt < QT; qt++) {
-                const int q = 32 * qt + c.r;
-                const bool qv = q < c.HW;
-                u32x4 g[4];
+                const int qc = 16 * qt + c.r;
+                const bool qv = qc < c.HW;
+                u32x4 g = gn;
                 if (pass == 1) {
-#pragma unroll
-                    for (int qd = 0; qd < 4; qd++) g[qd] = gn[qd];
                     if (qt + 1 < QT) g3_load(it, qt + 1, gn);
                     else g3_load(it + G::NW, 0, gn);
                 }
-                f32x16 acc;
-#pragma unroll
-                for (int i = 0; i < 16; i++) acc[i] = 0.f;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < KSB; ks++) {
-                    const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(arow + 32 * ks));
-                    acc = MFMA(a, __builtin_bit_cast(bf16x8, wreg[ks][qt]), acc);
+                    const opx8 av = __builtin_bit_cast(opx8, *reinterpret_cast<const u32x4*>(arow + 64 * ks));
+                    acc = MFMA(av, __builtin_bit_cast(opx8, wreg[ks][qt]), acc);
                 }
                 if (pass == 0) {
                     if (qv) {
 #pragma unroll
-                        for (int i = 0; i < 16; i++) {
+                        for (int i = 0; i < 4; i++) {
                             const float x = acc[i] + bias[qt];
                             ps += x;
                             pq = fmaf(x, x, pq);
@@ -1340,10 +1415,11 @@ __device__ __forceinline__ void bcast_body(Ctx& c, const Col (&k)[G::NC], const 
                 } else if (qv) {
                     const float bmean = bstat[2 * bd], brstd = bstat[2 * bd + 1];
 #pragma unroll
-                    for (int i = 0; i < 16; i++) acc[i] += bias[qt];
-                    float y[16];
+                    for (int i = 0; i < 4; i++) acc[i] += bias[qt];
+                    float y[4];
                     ln_apply(acc, bmean, brstd, g, y);
-                    img_store(img, RS, bd * c.HW + q, rtw, c.h, y);
+                    const int row = bd * c.HW + qc;
+                    *reinterpret_cast<u32x2*>(img + row * RS + swz(row, chunk) + half8) = (u32x2){pack2(y[0], y[1]), pack2(y[2], y[3])};
                 }
             }
             if (pass == 0) {
@@ -1361,9 +1437,9 @@ __device__ __forceinline__ void bcast_body(Ctx& c, const Col (&k)[G::NC], const 
             if ((int)threadIdx.x < NB) {
                 const int bd = threadIdx.x;
                 float s = 0.f, q = 0.f;
-                for (int j = 0; j < NRC; j++) {
-                    s += ipart[2 * (bd * NRC + j)];
-                    q += ipart[2 * (bd * NRC + j) + 1];
+                for (int j = 0; j < NTC; j++) {
+                    s += ipart[2 * (bd * NTC + j)];
+                    q += ipart[2 * (bd * NTC + j) + 1];
                 }
                 const float ninv = 1.0f / (float)(C * c.HW);
                 const float mean = s * ninv;
@@ -1377,34 +1453,32 @@ __device__ __forceinline__ void bcast_body(Ctx& c, const Col (&k)[G::NC], const 
     }
     // padded columns of the image (beyond NB*HW) feed only padded outputs, but must be finite
 #pragma unroll
-    for (int ct = 0; ct < NC; ct++)
+    for (int ct = 0; ct < NCL; ct++)
         if (!k[ct].valid) {
 #pragma unroll
-            for (int rt = 0; rt < NRCW; rt++) {
-                const unsigned o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                img_store_pk(img, RS, k[ct].col, c.wr * NRCW + rt, c.h, o);
-            }
+            for (int s = 0; s < NTCW / 2; s++)
+                img_store8(img, RS, k[ct].col, (4 * c.wr + c.q) * (NTCW / 2) + s, (u32x4){0, 0, 0, 0});
         }
     lds_barrier();   // image complete, TB dead: region 2 is the ring again
     STAMP(c, ST_BCAST);
     // c2: 1x1 conv C -> C on the image (own columns), accumulated into X
-    ring.issue(FS0);
-    ring.issue(FS1);
-    conv_lds<G, KSC, 1, NRC, NRCW, RS>(c, k, ring, X, nx0, nx1);
+    ring.issue(c, FS0);
+    ring.issue(c, FS1);
+    conv_lds<G, KSC, 1, NTC, NTCW, RS>(c, k, ring, X, nx0, nx1);
 }
 
 template <class G, int KSB>
 __global__ __launch_bounds__(G::NT, G::WPE) void k_bcast(NetDims d, TowerDev tw, NetIO io, LdsPlan L, int NB, int blk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int C = G::C, NRCW = G::NRCW, NC = G::NC;
+    constexpr int C = G::C, NTCW = G::NTCW, NCL = G::NCL;
     Ctx c;
     ctx_init<G>(c, smem, L, d, NB);
-    Col k[NC];
-    if (!setup<IN_X, NC>(d, io, NB, c, k)) return;
+    Col k[NCL];
+    if (!setup<IN_X, NCL>(d, io, NB, c, k)) return;
     WRing<G::NW, G::SM> ring;
-    f32x16 X[NRCW][NC];
+    f32x4 X[NTCW][NCL];
     bcast_body<G, KSB>(c, k, tw, io, L, smem, ring, X, NB, blk, 0, 0);
-    x_store<NRCW, NC>(c, k, io.pool, C, X);
+    x_store<NTCW, NCL>(c, k, io.pool, C, X);
     STAMP(c, ST_XSTORE);
     STAMP_PRINT(c, "bcast");
 }
@@ -1413,20 +1487,19 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_bcast(NetDims d, TowerDev tw,
 // one X round trip through HBM and one launch boundary less than k_bcast + k_seg<IN_X>.  Runs on the broadcast
 // kernel's LDS plan (its image holds C channels, enough for the bottleneck images).
 // The whole tower in one launch when it holds one broadcast block (Go): conv0 + blocks 0..blk-1 + broadcast block blk +
-// blocks blk+1..R-1 + tail.  X never travels between launches; it is parked in the destination slot only across the
-// middle of the broadcast block.
+// blocks blk+1..R-1 + tail.  X never leaves the registers.
 template <class G, int IN, int KSB, int OUT>
 __global__ __launch_bounds__(G::NT, G::WPE) void k_tower(NetDims d, TowerDev tw, HeadDev hd, NetIO io, LdsPlan L, int NB, int blk,
                                               int b1) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NRCW = G::NRCW, NC = G::NC;
+    constexpr int NTCW = G::NTCW, NCL = G::NCL;
     using BS = BlockStages<G>;
     Ctx c;
     ctx_init<G>(c, smem, L, d, NB);
-    Col k[NC];
-    if (!setup<IN, NC>(d, io, NB, c, k)) return;
+    Col k[NCL];
+    if (!setup<IN, NCL>(d, io, NB, c, k)) return;
     WRing<G::NW, G::SM> ring;
-    f32x16 X[NRCW][NC];
+    f32x4 X[NTCW][NCL];
     seg_front<G, IN>(c, k, d, tw, io, L, smem, ring, X, NB, 0, blk);
     seg_rest<G, OUT_REGS>(c, k, d, tw, hd, io, L, smem, ring, X, NB, 0, blk);
     const int b0 = blk + 1;
@@ -1439,14 +1512,14 @@ template <class G, int IN, int KSB, int OUT>
 __global__ __launch_bounds__(G::NT, G::WPE) void k_tower2(NetDims d, TowerDev tw, HeadDev hd, NetIO io, LdsPlan L, int NB, int blk,
                                                int blk2, int b1) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NRCW = G::NRCW, NC = G::NC;
+    constexpr int NTCW = G::NTCW, NCL = G::NCL;
     using BS = BlockStages<G>;
     Ctx c;
     ctx_init<G>(c, smem, L, d, NB);
-    Col k[NC];
-    if (!setup<IN, NC>(d, io, NB, c, k)) return;
+    Col k[NCL];
+    if (!setup<IN, NCL>(d, io, NB, c, k)) return;
     WRing<G::NW, G::SM> ring;
-    f32x16 X[NRCW][NC];
+    f32x4 X[NTCW][NCL];
     seg_front<G, IN>(c, k, d, tw, io, L, smem, ring, X, NB, 0, blk);
     seg_rest<G, OUT_REGS>(c, k, d, tw, hd, io, L, smem, ring, X, NB, 0, blk);
     const int b0 = blk + 1;
@@ -1461,14 +1534,14 @@ template <class G, int KSB, int OUT>
 __global__ __launch_bounds__(G::NT, G::WPE) void k_bseg(NetDims d, TowerDev tw, HeadDev hd, NetIO io, LdsPlan L, int NB, int blk,
                                              int b0, int b1) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NRCW = G::NRCW, NC = G::NC;
+    constexpr int NTCW = G::NTCW, NCL = G::NCL;
     using BS = BlockStages<G>;
     Ctx c;
     ctx_init<G>(c, smem, L, d, NB);
-    Col k[NC];
-    if (!setup<IN_X, NC>(d, io, NB, c, k)) return;
+    Col k[NCL];
+    if (!setup<IN_X, NCL>(d, io, NB, c, k)) return;
     WRing<G::NW, G::SM> ring;
-    f32x16 X[NRCW][NC];
+    f32x4 X[NTCW][NCL];
     bcast_body<G, KSB>(c, k, tw, io, L, smem, ring, X, NB, blk, b0 < b1 ? BS::open0 : 0, b0 < b1 ? BS::open1 : 0);
     seg_rest<G, OUT>(c, k, d, tw, hd, io, L, smem, ring, X, NB, b0, b1);
 }
@@ -1481,62 +1554,70 @@ inline unsigned short f2bf(float f) {
     u += 0x7fffu + ((u >> 16) & 1u);
     return (unsigned short)(u >> 16);
 }
-inline unsigned short f2h(float f);
-// fp32 -> MFMA operand element (round to nearest even)
-inline unsigned short f2op(float f) { return MZ_F16 ? f2h(f) : f2bf(f); }
 inline unsigned short f2h(float f) {
     _Float16 h = (_Float16)f;
     unsigned short u;
     std::memcpy(&u, &h, 2);
     return u;
 }
+// fp32 -> MFMA operand element (round to nearest even)
+inline unsigned short f2op(float f) { return MZ_F16 ? f2h(f) : f2bf(f); }
 
 struct FragWriter {
     std::vector<unsigned short>& out;
-    // w(row, k) -> weight for MFMA row (0..31) and k index (0..15) of this fragment
+    // w(row, k) -> weight for MFMA row (0..15) and k index (0..31) of this fragment: lane l holds A[l & 15][8 (l >> 4) + j]
     template <typename F>
     void frag(F w) {
         size_t base = out.size();
         out.resize(base + 512);
         for (int l = 0; l < 64; l++)
-            for (int j = 0; j < 8; j++) out[base + l * 8 + j] = f2op(w(l & 31, 8 * (l >> 5) + j));
+            for (int j = 0; j < 8; j++) out[base + l * 8 + j] = f2op(w(l & 15, 8 * (l >> 4) + j));
     }
 };
 
-// conv W[Cout][Cin][taps]: fragment order (tap, ks, ro) with natural k; ks runs to cin_pad/16
-// (cin_use < Cin: only the first cin_use input channels of the tensor are packed)
-void pack_conv(FragWriter& fw, const float* W, int Cout, int Cin, int taps, int cin_pad, int cin_use = -1) {
+// Channel at position pos of an image row written by ln_to_image / seg_front from accumulator tiles: Cn channels held by WR
+// wave rows of NTW = Cn / 16 / WR row tiles each; position = ((4 wr + q) * NTW + t) * 4 + e <-> channel 16 (NTW wr + t) + 4q + e.
+inline int image_channel(int pos, int Cn, int WR) {
+    const int NTW = Cn / 16 / WR;
+    const int e = pos & 3, u = pos >> 2, t = u % NTW, wq = u / NTW, q = wq & 3, wr = wq >> 2;
+    return 16 * (NTW * wr + t) + 4 * q + e;
+}
+
+// conv W[Cout][Cin][taps] read through an LDS image: fragment order (tap, ks, ro); k-step ks covers image positions
+// 32 ks .. 32 ks + 31.  wr_in = 0: the image holds the channels in natural order (the observation planes; the first cin_use
+// input channels of the tensor are packed, zero beyond), else the order of image_channel(., cin_pad, wr_in).
+void pack_conv(FragWriter& fw, const float* W, int Cout, int Cin, int taps, int cin_pad, int wr_in, int cin_use = -1) {
     if (cin_use < 0) cin_use = Cin;
     for (int t = 0; t < taps; t++)
-        for (int ks = 0; ks < cin_pad / 16; ks++)
-            for (int ro = 0; ro < Cout / 32; ro++)
+        for (int ks = 0; ks < cin_pad / 32; ks++)
+            for (int ro = 0; ro < Cout / 16; ro++)
                 fw.frag([&](int row, int kp) {
-                    const int ci = 16 * ks + kp;
+                    const int pos = 32 * ks + kp;
+                    const int ci = wr_in ? image_channel(pos, cin_pad, wr_in) : pos;
                     if (ci >= cin_use) return 0.f;
-                    return W[((size_t)(32 * ro + row) * Cin + ci) * taps + t];
+                    return W[((size_t)(16 * ro + row) * Cin + ci) * taps + t];
                 });
 }
-// 1x1 conv whose B operands come from registers (ln_to_regs): k-step ks, k index kp <-> input channel
-// 32(ks >> 1) + 16(ks & 1) + 4(kp >> 3) + (kp & 3) + 8((kp & 7) >> 2)
+// 1x1 conv whose B operands come from registers (ln_to_regs): k-step ks, k index kp = 8q + j <-> input channel
+// 16 (2 ks + (j >> 2)) + 4q + (j & 3)
 void pack_conv_kperm(FragWriter& fw, const float* W, int Cout, int Cin) {
-    for (int ks = 0; ks < Cin / 16; ks++)
-        for (int ro = 0; ro < Cout / 32; ro++)
+    for (int ks = 0; ks < Cin / 32; ks++)
+        for (int ro = 0; ro < Cout / 16; ro++)
             fw.frag([&](int row, int kp) {
-                const int ci = 32 * (ks >> 1) + 16 * (ks & 1) + 4 * (kp >> 3) + (kp & 3) + 8 * ((kp & 7) >> 2);
-                return W[(size_t)(32 * ro + row) * Cin + ci];
+                const int q = kp >> 3, j = kp & 7;
+                const int ci = 16 * (2 * ks + (j >> 2)) + 4 * q + (j & 3);
+                return W[(size_t)(16 * ro + row) * Cin + ci];
             });
 }
-// gamma/beta [Cn][HW] -> fp16 [rt][qd][h][HW+1]{g0..3, b0..3}: lane (cell p, half h) of row tile rt reads
-// channels 32rt + 8qd + 4h + e; entry HW is all zero (padded columns)
+// gamma/beta [Cn][HW] -> fp16 [channel quad][HW+1]{g0..3, b0..3}: lane (cell p, quarter q) of row tile t reads
+// channels 16t + 4q + e = quad 4t + q; entry HW is all zero (padded columns)
 void pack_gb(std::vector<unsigned short>& out, const float* g, const float* b, int Cn, int HW) {
-    for (int rt = 0; rt < Cn / 32; rt++)
-        for (int qd = 0; qd < 4; qd++)
-            for (int h = 0; h < 2; h++)
-                for (int p = 0; p <= HW; p++) {
-                    const int ch = 32 * rt + 8 * qd + 4 * h;
-                    for (int e = 0; e < 4; e++) out.push_back(p < HW ? f2h(g[(size_t)(ch + e) * HW + p]) : 0);
-                    for (int e = 0; e < 4; e++) out.push_back(p < HW ? f2h(b[(size_t)(ch + e) * HW + p]) : 0);
-                }
+    for (int cq = 0; cq < Cn / 4; cq++)
+        for (int p = 0; p <= HW; p++) {
+            const int ch = 4 * cq;
+            for (int e = 0; e < 4; e++) out.push_back(p < HW ? f2h(g[(size_t)(ch + e) * HW + p]) : 0);
+            for (int e = 0; e < 4; e++) out.push_back(p < HW ? f2h(b[(size_t)(ch + e) * HW + p]) : 0);
+        }
 }
 
 struct TowerHost {
@@ -1571,46 +1652,50 @@ bool shape_supported(const NetDims& d) {
 
 int align16(int x) { return (x + 15) / 16 * 16; }
 
-void plan_tail(LdsPlan& L, int end, int NW, int Cb) {
+// per-workgroup statistics area (floats): wpart [2][NB][NW][2], ipart [NB * C/16][2], bstat [NB][2]
+int stat_floats(int NB, int NW, int C) { return 4 * NB * NW + 2 * NB * (C / 16) + 2 * NB; }
+
+void plan_tail(LdsPlan& L, int end, int NB, int NW, int C, int Cb) {
     end = align16(end);
     while ((end - L.img_off) % 256) end += 16;   // zero rows start at the image's bank phase
     L.zrow_off = end;
-    const int rest = (2 * MAXNB * NW * 2 + 2 * 256 + 2 * MAXNB) * 4 + 4 * MAXNB * 4 + 16;
-    L.zstride = 2 * Cb + 16;
+    const int stat = align16(stat_floats(NB, NW, C) * 4);
+    const int rest = stat + 4 * MAXNB * 4 + 16;
+    L.zstride = 2 * Cb + 32;
     L.zbytes = ZROWS * L.zstride;
-    if (L.zbytes < 1024) L.zbytes = 1024;        // conv0 reads up to (C + 16) * 2 + 16 bytes of zero row 0
-    if (end + L.zbytes + rest > 160 * 1024) {    // no room for 16 rows (Go 5x5's broadcast plan): one shared zero row
+    if (L.zbytes < 1024) L.zbytes = 1024;        // conv0 reads up to 2 C bytes of zero row 0
+    if (end + L.zbytes + rest > 160 * 1024) {    // no room for 16 rows: one shared zero row
         L.zstride = 0;
         L.zbytes = 1024;
     }
     end += L.zbytes;
     L.stat_off = end;
-    end += (2 * MAXNB * NW * 2 + 2 * 256 + 2 * MAXNB) * 4;  // wpart x2, ipart, bstat
+    end += stat;
     L.meta_off = end;
     end += 4 * MAXNB * 4;
     L.total = align16(end);
 }
 
 // k_seg: [ring][image]
-LdsPlan make_plan_seg(const NetDims& d, int COLS, int NW, int SM) {
+LdsPlan make_plan_seg(const NetDims& d, int COLS, int NB, int NW, int SM) {
     LdsPlan L{};
-    const int rs0 = d.C * 2 + 16;
+    const int rs0 = d.C * 2 + 32;
     // the ring comes first: LDS-DMA destinations stay below 64 KiB
     L.ring_off = 0;
     L.img_off = NSLOT * SM * 1024;
     L.img0_off = L.img_off;
     int end = L.img_off + align16(COLS * rs0);
     L.head_off = 0;
-    plan_tail(L, end, NW, d.Cb);
+    plan_tail(L, end, NB, NW, d.C, d.Cb);
     return L;
 }
-// k_bcast: [region 2 = ring / TB][image, C channels].  with_conv0 (the one-launch towers): conv0's wider input image lies
+// k_bcast: [region 2 = ring / TB][image, C channels].  with_conv0 (the one-launch towers): conv0's input image lies
 // right behind the ring, over the tail of the TB region and the block image - both are dead while conv0 runs.
 LdsPlan make_plan_bcast(const NetDims& d, int COLS, int NB, int NW, int SM, bool with_conv0 = false) {
     LdsPlan L{};
-    const int rsc = d.C * 2 + 16, rs0 = d.C * 2 + 16;
-    L.kp = (d.HW + 15) / 16 * 16;
-    L.qt = (d.HW + 31) / 32;
+    const int rsc = d.C * 2 + 32, rs0 = d.C * 2 + 32;
+    L.kp = (d.HW + 31) / 32 * 32;
+    L.qt = L.kp / 16;
     L.tbs = (NB * L.kp + 8) * 2;
     const int ring = NSLOT * SM * 1024, tbb = align16(d.C * L.tbs);
     L.ring_off = 0;
@@ -1619,7 +1704,7 @@ LdsPlan make_plan_bcast(const NetDims& d, int COLS, int NB, int NW, int SM, bool
     L.img0_off = with_conv0 ? ring : L.img_off;
     int end = L.img_off + align16(COLS * rsc);
     if (with_conv0 && L.img0_off + align16(COLS * rs0) > end) end = L.img0_off + align16(COLS * rs0);
-    plan_tail(L, end, NW, d.Cb);
+    plan_tail(L, end, NB, NW, d.C, d.Cb);
     return L;
 }
 
@@ -1677,12 +1762,11 @@ MfmaNet* mfma_create(const NetDims& d, int max_batch, std::string* err) {
         delete n;
         return nullptr;
     }
-    n->Lseg = make_plan_seg(d, n->COLS, n->NW, n->SM);
+    n->Lseg = make_plan_seg(d, n->COLS, n->NB, n->NW, n->SM);
     n->Lbc = make_plan_bcast(d, n->COLS, n->NB, n->NW, n->SM);
     n->Ltw = make_plan_bcast(d, n->COLS, n->NB, n->NW, n->SM, true);
-    const int bc_items = n->NB * (d.C / 32) * n->Lbc.qt;
     const bool has_bcast = d.bcast_every_n > 0 && d.R >= d.bcast_every_n;
-    if (n->Lseg.total > 160 * 1024 || (has_bcast && (n->Lbc.total > 160 * 1024 || bc_items > 256))) {
+    if (n->Lseg.total > 160 * 1024 || (has_bcast && n->Lbc.total > 160 * 1024)) {
         if (err) *err = "LDS plan does not fit 160 KiB";
         delete n;
         return nullptr;
@@ -1720,11 +1804,12 @@ int mfma_pack_weights(MfmaNet* n, const NetDims& d, const float* blob, size_t co
     TowerHost th[2];
     const int cin0[2] = {d.O, C + d.a};
     const int cin0_pad[2] = {32, C};   // dynamics: the C hidden-state channels; the action planes go through TowerDev::wact
+    const int WRG = n->WR;              // wave rows: decides the channel order of the LDS images (image_channel)
     for (int t = 0; t < 2; t++) {
         TowerHost& T = th[t];
         FragWriter fw{T.stream};
         const float* w0 = take((size_t)C * cin0[t] * 9);
-        pack_conv(fw, w0, C, cin0[t], 9, cin0_pad[t], t == 0 ? cin0[t] : C);
+        pack_conv(fw, w0, C, cin0[t], 9, cin0_pad[t], t == 0 ? 0 : WRG, t == 0 ? cin0[t] : C);
         if (t == 1) {
             T.wact.assign((size_t)d.a * 9 * C, 0.f);
             for (int pl = 0; pl < d.a; pl++)
@@ -1743,11 +1828,11 @@ int mfma_pack_weights(MfmaNet* n, const NetDims& d, const float* blob, size_t co
                 const float *g3 = take((size_t)Cb * HW), *b3 = take((size_t)Cb * HW), *c3 = take((size_t)Cb * Cb * 9);
                 const float *g4 = take((size_t)Cb * HW), *b4 = take((size_t)Cb * HW), *c4 = take((size_t)C * Cb);
                 if (n->WR == 1) pack_conv_kperm(fw, c1, Cb, C);
-                else pack_conv(fw, c1, Cb, C, 1, C);
-                pack_conv(fw, c2, Cb, Cb, 9, Cb);
-                pack_conv(fw, c3, Cb, Cb, 9, Cb);
+                else pack_conv(fw, c1, Cb, C, 1, C, WRG);
+                pack_conv(fw, c2, Cb, Cb, 9, Cb, WRG);
+                pack_conv(fw, c3, Cb, Cb, 9, Cb, WRG);
                 if (n->WR == 1) pack_conv_kperm(fw, c4, C, Cb);
-                else pack_conv(fw, c4, C, Cb, 1, Cb);
+                else pack_conv(fw, c4, C, Cb, 1, Cb, WRG);
                 pack_gb(T.gb, g1, b1, C, HW);
                 pack_gb(T.gb, g2, b2, Cb, HW);
                 pack_gb(T.gb, g3, b3, Cb, HW);
@@ -1757,22 +1842,22 @@ int mfma_pack_weights(MfmaNet* n, const NetDims& d, const float* blob, size_t co
                 const float *g2 = take((size_t)C * HW), *b2 = take((size_t)C * HW);
                 const float *wb = take((size_t)HW * HW), *bbv = take((size_t)HW);
                 const float *g3 = take((size_t)C * HW), *b3 = take((size_t)C * HW), *c2 = take((size_t)C * C);
-                pack_conv(fw, c1, C, C, 1, C);
-                pack_conv(fw, c2, C, C, 1, C);
+                pack_conv(fw, c1, C, C, 1, C, WRG);
+                pack_conv(fw, c2, C, C, 1, C, WRG);
                 pack_gb(T.gb, g1, b1, C, HW);
                 pack_gb(T.gb, g2, b2, C, HW);
                 pack_gb(T.gb, g3, b3, C, HW);
-                // B fragments of the broadcast linear: lane (q = 32qt + r, h) holds Wb[q][16ks + 8h + j]
+                // B fragments of the broadcast linear: lane (r, q) holds Wb[cell 16qt + r][32ks + 8q + j]
                 const int KP = n->Lbc.kp, QT = n->Lbc.qt;
                 T.dev.wboff[i] = (int)(T.wbf.size() / 8);
                 T.dev.bboff[i] = (int)T.bb.size();
-                T.bb.resize(T.bb.size() + (size_t)QT * 32, 0.f);
+                T.bb.resize(T.bb.size() + (size_t)QT * 16, 0.f);
                 for (int q = 0; q < HW; q++) T.bb[T.dev.bboff[i] + q] = bbv[q];
-                for (int ks = 0; ks < KP / 16; ks++)
+                for (int ks = 0; ks < KP / 32; ks++)
                     for (int qt = 0; qt < QT; qt++)
                         for (int l = 0; l < 64; l++)
                             for (int j = 0; j < 8; j++) {
-                                const int q = 32 * qt + (l & 31), p = 16 * ks + 8 * (l >> 5) + j;
+                                const int q = 16 * qt + (l & 15), p = 32 * ks + 8 * (l >> 4) + j;
                                 T.wbf.push_back((q < HW && p < HW) ? f2op(wb[(size_t)q * HW + p]) : 0);
                             }
             }
@@ -1862,18 +1947,18 @@ void launch_tower(MfmaNet* n, hipStream_t st, int grid, const NetDims& d, const 
     hipLaunchKernelGGL((k_tower<G, IN, KSB, OUT_FINAL>), dim3(grid), dim3(G::NT), n->Ltw.total, st, d, tw, n->hd, io, n->Ltw,
                        n->NB, blk, d.R);
 }
-// one launch for towers with a single broadcast block on the board sizes of the reference's games (k-step counts 2, 4, 6
-// of the broadcast linear: 25-, 49- and 81-cell boards) and the two-waves-per-SIMD geometries; false: not this shape
+// one launch for towers with a single broadcast block (k-step counts 1, 2, 3 of the broadcast linear: boards of up to 32,
+// 64 and 96 cells) on the two-waves-per-SIMD geometries; false: not this shape
 template <class G, int IN>
 bool try_launch_tower(MfmaNet* n, hipStream_t st, int grid, const NetDims& d, const TowerDev& tw, const NetIO& io, int blk) {
     if constexpr (G::NC != 1) {
         return false;
     } else {
         if (n->Ltw.total > 160 * 1024) return false;
-        switch (n->Lbc.kp / 16) {
+        switch (n->Lbc.kp / 32) {
+            case 1: launch_tower<G, IN, 1>(n, st, grid, d, tw, io, blk); return true;
             case 2: launch_tower<G, IN, 2>(n, st, grid, d, tw, io, blk); return true;
-            case 4: launch_tower<G, IN, 4>(n, st, grid, d, tw, io, blk); return true;
-            case 6: launch_tower<G, IN, 6>(n, st, grid, d, tw, io, blk); return true;
+            case 3: launch_tower<G, IN, 3>(n, st, grid, d, tw, io, blk); return true;
             default: return false;
         }
     }
@@ -1885,9 +1970,9 @@ bool try_launch_tower2(MfmaNet* n, hipStream_t st, int grid, const NetDims& d, c
     if constexpr (G::NC != 1 || G::C != 128) {
         return false;
     } else {
-        if (n->Ltw.total > 160 * 1024 || n->Lbc.kp / 16 != 4) return false;
-        lds_optin(reinterpret_cast<const void*>(&k_tower2<G, IN, 4, OUT_FINAL>));
-        hipLaunchKernelGGL((k_tower2<G, IN, 4, OUT_FINAL>), dim3(grid), dim3(G::NT), n->Ltw.total, st, d, tw, n->hd, io, n->Ltw,
+        if (n->Ltw.total > 160 * 1024 || n->Lbc.kp / 32 != 2) return false;
+        lds_optin(reinterpret_cast<const void*>(&k_tower2<G, IN, 2, OUT_FINAL>));
+        hipLaunchKernelGGL((k_tower2<G, IN, 2, OUT_FINAL>), dim3(grid), dim3(G::NT), n->Ltw.total, st, d, tw, n->hd, io, n->Ltw,
                            n->NB, blk, blk2, d.R);
         return true;
     }
@@ -1895,13 +1980,10 @@ bool try_launch_tower2(MfmaNet* n, hipStream_t st, int grid, const NetDims& d, c
 template <class G, int OUT>
 void launch_bseg_k(MfmaNet* n, hipStream_t st, int grid, const NetDims& d, const TowerDev& tw, const NetIO& io, int blk, int b0,
                    int b1) {
-    switch (n->Lbc.kp / 16) {
+    switch (n->Lbc.kp / 32) {
         case 1: launch_bseg<G, 1, OUT>(n, st, grid, d, tw, io, blk, b0, b1); break;
         case 2: launch_bseg<G, 2, OUT>(n, st, grid, d, tw, io, blk, b0, b1); break;
-        case 3: launch_bseg<G, 3, OUT>(n, st, grid, d, tw, io, blk, b0, b1); break;
-        case 4: launch_bseg<G, 4, OUT>(n, st, grid, d, tw, io, blk, b0, b1); break;
-        case 5: launch_bseg<G, 5, OUT>(n, st, grid, d, tw, io, blk, b0, b1); break;
-        default: launch_bseg<G, 6, OUT>(n, st, grid, d, tw, io, blk, b0, b1); break;
+        default: launch_bseg<G, 3, OUT>(n, st, grid, d, tw, io, blk, b0, b1); break;
     }
 }
 
@@ -1913,8 +1995,8 @@ int forward_t(MfmaNet* n, hipStream_t st, bool initial, const NetDims& d, const 
     {
         int e = 0;
         while (e < d.R && tw.type[e] == 0) e++;
-        if (initial) launch_tower<G, IN_OBS, 6>(n, st, grid, d, tw, io, e);
-        else launch_tower<G, IN_HIDDEN, 6>(n, st, grid, d, tw, io, e);
+        if (initial) launch_tower<G, IN_OBS, 3>(n, st, grid, d, tw, io, e);
+        else launch_tower<G, IN_HIDDEN, 3>(n, st, grid, d, tw, io, e);
         hipLaunchKernelGGL(k_heads, dim3((io.B + HS - 1) / HS), dim3(HT), heads_lds_bytes(d), st, d, n->hd, io);
         return 0;
     }
@@ -1992,13 +2074,10 @@ int forward_t(MfmaNet* n, hipStream_t st, bool initial, const NetDims& d, const 
         if (last) hipLaunchKernelGGL(k_heads, dim3((io.B + HS - 1) / HS), dim3(HT), heads_lds_bytes(d), st, d, n->hd, io);
         first = false;
         if (last || (dbg_stop >= 0 && dbg_stop == e)) break;
-        switch (n->Lbc.kp / 16) {
+        switch (n->Lbc.kp / 32) {
             case 1: launch_bcast<G, 1>(n, st, grid, d, tw, io, e); break;
             case 2: launch_bcast<G, 2>(n, st, grid, d, tw, io, e); break;
-            case 3: launch_bcast<G, 3>(n, st, grid, d, tw, io, e); break;
-            case 4: launch_bcast<G, 4>(n, st, grid, d, tw, io, e); break;
-            case 5: launch_bcast<G, 5>(n, st, grid, d, tw, io, e); break;
-            default: launch_bcast<G, 6>(n, st, grid, d, tw, io, e); break;
+            default: launch_bcast<G, 3>(n, st, grid, d, tw, io, e); break;
         }
         b = e + 1;
     }
