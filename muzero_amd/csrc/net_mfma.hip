@@ -66,6 +66,8 @@
 #define mfma_tile_boards mfma_tile_boards_bf16
 #endif
 
+#include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -430,13 +432,29 @@ __device__ __forceinline__ void ln_apply(const f32x16& v, float mean, float rstd
     }
 }
 
-// Packed variant: o[j] = bf16x2 of relu(LN(v)) rows (2j, 2j+1).  Per element: half a v_pk_fma_f32
-// (normalise), one v_fma_mix_f32 (fp16 gamma/beta), half a v_cvt_pk_bf16_f32 and half a v_pk_max_i16
-// (ReLU on the packed bf16 pair: a negative bf16 is a negative int16).
+// Packed variant: o[j] = 16-bit pair of relu(LN(v)) rows (2j, 2j+1).
+// bf16 operands: per element half a v_pk_fma_f32 (normalise), one v_fma_mix_f32 (fp16 gamma/beta), half a v_cvt_pk_bf16_f32
+// and half a v_pk_max_i16 (ReLU on the packed pair: a negative bf16 is a negative int16) = 2.5 instructions.
+// fp16 operands: half a v_pk_fma_f32 and one v_fma_mixlo/mixhi_f16 with the clamp modifier = 1.5 instructions: the mix-FMA
+// rounds straight to the fp16 half of the result register, and its clamp to [0, 1] IS the ReLU because the table holds
+// gamma / S and beta / S (S a power of two >= the largest value the LayerNorm can put out, ln_scale() on the host) and the conv
+// that reads these activations has its weights multiplied by S: the same products bit for bit (power-of-two scaling), except
+// that activations below S * 2^-14 are fp16 subnormals (absolute error <= S * 2^-25).
 __device__ __forceinline__ void ln_apply_pk(const f32x16& v, float rstd, float nmr, const u32x4 (&g)[4], unsigned (&o)[8]) {
     const f32x2 a2 = {rstd, rstd}, n2 = {nmr, nmr};
 #pragma unroll
     for (int qd = 0; qd < 4; qd++) {
+#if MZ_F16
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) {
+            f32x2 x = {v[4 * qd + e], v[4 * qd + e + 1]};
+            f32x2 t = x * a2 + n2;
+            unsigned pk;
+            asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[0,1,1] clamp" : "=v"(pk) : "v"(t.x), "v"(g[qd][e / 2]), "v"(g[qd][2 + e / 2]));
+            asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[0,1,1] clamp" : "+v"(pk) : "v"(t.y), "v"(g[qd][e / 2]), "v"(g[qd][2 + e / 2]));
+            o[2 * qd + e / 2] = pk;
+        }
+#else
         f16x8 hv = __builtin_bit_cast(f16x8, g[qd]);
 #pragma unroll
         for (int e = 0; e < 4; e += 2) {
@@ -449,6 +467,7 @@ __device__ __forceinline__ void ln_apply_pk(const f32x16& v, float rstd, float n
             s16x2 r = __builtin_elementwise_max(__builtin_bit_cast(s16x2, pk), (s16x2){0, 0});
             o[2 * qd + e / 2] = __builtin_bit_cast(unsigned, r);
         }
+#endif
     }
 }
 // 16 rows of global row tile rt, as packed bf16 pairs, into the [column][channel] image (row stride rs)
@@ -1505,7 +1524,7 @@ struct FragWriter {
 
 // conv W[Cout][Cin][taps]: fragment order (tap, ks, ro) with natural k; ks runs to cin_pad/16
 // (cin_use < Cin: only the first cin_use input channels of the tensor are packed)
-void pack_conv(FragWriter& fw, const float* W, int Cout, int Cin, int taps, int cin_pad, int cin_use = -1) {
+void pack_conv(FragWriter& fw, const float* W, int Cout, int Cin, int taps, int cin_pad, int cin_use = -1, float ws = 1.f) {
     if (cin_use < 0) cin_use = Cin;
     for (int t = 0; t < taps; t++)
         for (int ks = 0; ks < cin_pad / 16; ks++)
@@ -1513,30 +1532,49 @@ void pack_conv(FragWriter& fw, const float* W, int Cout, int Cin, int taps, int 
                 fw.frag([&](int row, int kp) {
                     const int ci = 16 * ks + kp;
                     if (ci >= cin_use) return 0.f;
-                    return W[((size_t)(32 * ro + row) * Cin + ci) * taps + t];
+                    return ws * W[((size_t)(32 * ro + row) * Cin + ci) * taps + t];
                 });
 }
 // 1x1 conv whose B operands come from registers (ln_to_regs): k-step ks, k index kp <-> input channel
 // 32(ks >> 1) + 16(ks & 1) + 4(kp >> 3) + (kp & 3) + 8((kp & 7) >> 2)
-void pack_conv_kperm(FragWriter& fw, const float* W, int Cout, int Cin) {
+void pack_conv_kperm(FragWriter& fw, const float* W, int Cout, int Cin, float ws = 1.f) {
     for (int ks = 0; ks < Cin / 16; ks++)
         for (int ro = 0; ro < Cout / 32; ro++)
             fw.frag([&](int row, int kp) {
                 const int ci = 32 * (ks >> 1) + 16 * (ks & 1) + 4 * (kp >> 3) + (kp & 3) + 8 * ((kp & 7) >> 2);
-                return W[(size_t)(32 * ro + row) * Cin + ci];
+                return ws * W[(size_t)(32 * ro + row) * Cin + ci];
             });
 }
 // gamma/beta [Cn][HW] -> fp16 [rt][qd][h][HW+1]{g0..3, b0..3}: lane (cell p, half h) of row tile rt reads
 // channels 32rt + 8qd + 4h + e; entry HW is all zero (padded columns)
-void pack_gb(std::vector<unsigned short>& out, const float* g, const float* b, int Cn, int HW) {
+void pack_gb(std::vector<unsigned short>& out, const float* g, const float* b, int Cn, int HW, float inv_s = 1.f) {
     for (int rt = 0; rt < Cn / 32; rt++)
         for (int qd = 0; qd < 4; qd++)
             for (int h = 0; h < 2; h++)
                 for (int p = 0; p <= HW; p++) {
                     const int ch = 32 * rt + 8 * qd + 4 * h;
-                    for (int e = 0; e < 4; e++) out.push_back(p < HW ? f2h(g[(size_t)(ch + e) * HW + p]) : 0);
-                    for (int e = 0; e < 4; e++) out.push_back(p < HW ? f2h(b[(size_t)(ch + e) * HW + p]) : 0);
+                    for (int e = 0; e < 4; e++) out.push_back(p < HW ? f2h(inv_s * g[(size_t)(ch + e) * HW + p]) : 0);
+                    for (int e = 0; e < 4; e++) out.push_back(p < HW ? f2h(inv_s * b[(size_t)(ch + e) * HW + p]) : 0);
                 }
+}
+
+// Scale S of a LayerNorm whose output goes through ln_apply_pk (see there): the power of two >= 256 that bounds
+// |gamma| * sqrt(N - 1) + |beta| (no LayerNorm output of N elements exceeds sqrt(N - 1) in magnitude), so the clamp of the
+// fp16 mix-FMA never cuts a value.  1 for bf16 operands (ReLU by integer max there).  0: the affine is too large for the
+// fp16 path (S beyond 2^13 would push typical activations into the subnormals), or the consumer's weights would overflow.
+float ln_scale(const float* g, const float* b, int Cn, int HW, const float* W, size_t wcount) {
+    if (!MZ_F16) return 1.f;
+    float gm = 0.f, bm = 0.f, wm = 0.f;
+    for (size_t i = 0; i < (size_t)Cn * HW; i++) {
+        gm = std::max(gm, std::fabs(g[i]));
+        bm = std::max(bm, std::fabs(b[i]));
+    }
+    for (size_t i = 0; i < wcount; i++) wm = std::max(wm, std::fabs(W[i]));
+    const float bound = gm * std::sqrt((float)(Cn * HW)) + bm;
+    float S = 256.f;
+    while (S < bound) S *= 2.f;
+    if (!(S <= 8192.f) || !(wm * S < 60000.f)) return 0.f;
+    return S;
 }
 
 struct TowerHost {
@@ -1706,6 +1744,15 @@ void mfma_destroy(MfmaNet* n) {
     delete n;
 }
 
+namespace MZ_IMPL {
+int scale_error(std::string* err) {
+    if (err)
+        *err = "a LayerNorm's gamma / beta (or the weights of the conv behind it) are too large for the fp16-operand path's scaled "
+               "activations; use MZ_PRECISION_BF16 or MZ_PRECISION_FP32 for this network";
+    return -1;
+}
+}  // namespace MZ_IMPL
+
 int mfma_pack_weights(MfmaNet* n, const NetDims& d, const float* blob, size_t count, std::string* err) {
     for (int i = 0; i < n->nbufs; i++) (void)hipFree(n->bufs[i]);
     n->nbufs = 0;
@@ -1742,24 +1789,30 @@ int mfma_pack_weights(MfmaNet* n, const NetDims& d, const float* blob, size_t co
                 const float *g2 = take((size_t)Cb * HW), *b2 = take((size_t)Cb * HW), *c2 = take((size_t)Cb * Cb * 9);
                 const float *g3 = take((size_t)Cb * HW), *b3 = take((size_t)Cb * HW), *c3 = take((size_t)Cb * Cb * 9);
                 const float *g4 = take((size_t)Cb * HW), *b4 = take((size_t)Cb * HW), *c4 = take((size_t)C * Cb);
-                if (n->WR == 1) pack_conv_kperm(fw, c1, Cb, C);
-                else pack_conv(fw, c1, Cb, C, 1, C);
-                pack_conv(fw, c2, Cb, Cb, 9, Cb);
-                pack_conv(fw, c3, Cb, Cb, 9, Cb);
-                if (n->WR == 1) pack_conv_kperm(fw, c4, C, Cb);
-                else pack_conv(fw, c4, C, Cb, 1, Cb);
-                pack_gb(T.gb, g1, b1, C, HW);
-                pack_gb(T.gb, g2, b2, Cb, HW);
-                pack_gb(T.gb, g3, b3, Cb, HW);
-                pack_gb(T.gb, g4, b4, Cb, HW);
+                const float s1 = ln_scale(g1, b1, C, HW, c1, (size_t)Cb * C), s2 = ln_scale(g2, b2, Cb, HW, c2, (size_t)Cb * Cb * 9);
+                const float s3 = ln_scale(g3, b3, Cb, HW, c3, (size_t)Cb * Cb * 9), s4 = ln_scale(g4, b4, Cb, HW, c4, (size_t)C * Cb);
+                if (s1 == 0.f || s2 == 0.f || s3 == 0.f || s4 == 0.f) return scale_error(err);
+                if (n->WR == 1) pack_conv_kperm(fw, c1, Cb, C, s1);
+                else pack_conv(fw, c1, Cb, C, 1, C, -1, s1);
+                pack_conv(fw, c2, Cb, Cb, 9, Cb, -1, s2);
+                pack_conv(fw, c3, Cb, Cb, 9, Cb, -1, s3);
+                if (n->WR == 1) pack_conv_kperm(fw, c4, C, Cb, s4);
+                else pack_conv(fw, c4, C, Cb, 1, Cb, -1, s4);
+                pack_gb(T.gb, g1, b1, C, HW, 1.f / s1);
+                pack_gb(T.gb, g2, b2, Cb, HW, 1.f / s2);
+                pack_gb(T.gb, g3, b3, Cb, HW, 1.f / s3);
+                pack_gb(T.gb, g4, b4, Cb, HW, 1.f / s4);
             } else {
                 const float *g1 = take((size_t)C * HW), *b1 = take((size_t)C * HW), *c1 = take((size_t)C * C);
                 const float *g2 = take((size_t)C * HW), *b2 = take((size_t)C * HW);
                 const float *wb = take((size_t)HW * HW), *bbv = take((size_t)HW);
                 const float *g3 = take((size_t)C * HW), *b3 = take((size_t)C * HW), *c2 = take((size_t)C * C);
-                pack_conv(fw, c1, C, C, 1, C);
+                // LN1 goes through ln_apply_pk (scaled, c1 takes the scale); LN2 and LN3 through ln_apply (plain ReLU)
+                const float s1 = ln_scale(g1, b1, C, HW, c1, (size_t)C * C);
+                if (s1 == 0.f) return scale_error(err);
+                pack_conv(fw, c1, C, C, 1, C, -1, s1);
                 pack_conv(fw, c2, C, C, 1, C);
-                pack_gb(T.gb, g1, b1, C, HW);
+                pack_gb(T.gb, g1, b1, C, HW, 1.f / s1);
                 pack_gb(T.gb, g2, b2, C, HW);
                 pack_gb(T.gb, g3, b3, C, HW);
                 // B fragments of the broadcast linear: lane (q = 32qt + r, h) holds Wb[q][16ks + 8h + j]
