@@ -8,7 +8,8 @@ Inputs (observations, legal masks) and outputs are resident in HBM during the ti
 noise is drawn on the device (Philox, seed 7 - SURVEY.md §8d).  Games shard over GPUs (one process per
 GPU, no data-path collective); RCCL - through the C ABI, mz_comm_init / mz_broadcast_weights /
 mz_gather_stats - only broadcasts the weight blob before the timed region and gathers the per-rank
-statistics after it; torch.distributed only hands rank 0's RCCL id to the other ranks.
+statistics after it; torch.distributed only hands rank 0's RCCL id to the other ranks.  If RCCL cannot start the run
+fails (non-zero exit): no other transport is substituted.
 
   python bench.py --gpus 1 --steps 3 --warmup 1
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -87,9 +88,12 @@ def cpu_baseline(spec, weights, n, m, c_visit, bounds, games, seed, max_batch=10
     return sims / dt, sims, dt, torch.get_num_threads()
 
 
-def fp32_leg(spec, weights, n, m, c_visit, bounds, games, obs, device):
-    """The same search on the exact-fp32 network path (MZ_PRECISION_FP32: the reference's arithmetic, fp32 MFMA), one move of
-    `games` games after a warm-up move, every kernel on one stream and timed: an extra, separately labelled figure - never `value`."""
+def fp32_leg(spec, weights, n, m, c_visit, bounds, games, obs, device, moves):
+    """The same search on the exact-fp32 network path (MZ_PRECISION_FP32: the reference's own arithmetic,
+    InitialInferenceListTranslator.java:44-112 is fp32 end to end; here on v_mfma_f32_16x16x4_f32) at the same batch:
+    `moves` timed moves after a warm-up move, every kernel on one stream and timed with HIP events.  An extra, separately
+    labelled figure - never `value`.  `python bench.py --precision fp32` runs the whole bench on this path
+    (profiles/r3_fp32_kernel_stats.csv is rocprofv3's view of that)."""
     import torch
     from muzero_amd import capi, netspec
     ctx = capi.Context(capi.make_config(spec, n, m, c_visit, known_bounds=bounds, max_games=games,
@@ -109,18 +113,23 @@ def fp32_leg(spec, weights, n, m, c_visit, bounds, games, obs, device):
     ctx.search_moves(games, o, legal, outputs=outs)
     ctx.synchronize()
     ctx.set_timing(True)
+    sims, ms, cnt = 0, 0.0, 0
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ctx.search_moves(games, o, legal, outputs=outs)
+    for _ in range(moves):
+        ctx.search_moves(games, o, legal, outputs=outs)
+        sims += ctx.last_stats()[0]
+        t = ctx.get_timing()["recurrent"]
+        ms += t[0]
+        cnt += t[1]
     ctx.synchronize()
     torch.cuda.synchronize()
-    assert int(outs["status"].abs().sum().item()) == 0
     dt = time.perf_counter() - t0
-    sims, _ = ctx.last_stats()
-    ms, cnt = ctx.get_timing()["recurrent"]
+    assert int(outs["status"].abs().sum().item()) == 0
     ctx.close()
     tf = netspec.flops_per_sample(spec)["recurrent"] * games / (ms / max(cnt, 1) / 1e3) / 1e12 if ms > 0 else 0.0
-    return {"simulations_per_s": sims / dt, "games": games, "moves": 1, "dtype": "fp32",
-            "recurrent_ms": ms / max(cnt, 1), "achieved_tflops": tf, "peak_tflops": PEAK_TFLOPS["fp32"],
+    return {"simulations_per_s": sims / dt, "games": games, "moves": moves, "dtype": "fp32",
+            "recurrent_ms": ms / max(cnt, 1), "launches_timed": cnt, "achieved_tflops": tf, "peak_tflops": PEAK_TFLOPS["fp32"],
             "frac": tf / PEAK_TFLOPS["fp32"], "kernel": "k_net_fp32 (v_mfma_f32_16x16x4_f32 convs)"}
 
 
@@ -163,8 +172,10 @@ def main():
                     help="network arithmetic: fp32 exact kernels, or MFMA with bf16 / fp16 operands and fp32 accumulation")
     ap.add_argument("--cpu-games", type=int, default=1024, help="games in the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--fp32-games", type=int, default=4096,
-                    help="games of the extra exact-fp32 leg (the same search on MZ_PRECISION_FP32: v_mfma_f32_16x16x4_f32); 0 = skip")
+    ap.add_argument("--comm-timeout", type=float, default=300.0, help="N > 1: seconds allowed for the RCCL set-up before the run is ended")
+    ap.add_argument("--fp32-games", type=int, default=-1,
+                    help="games of the extra exact-fp32 leg (the same search on MZ_PRECISION_FP32: v_mfma_f32_16x16x4_f32, "
+                         "`steps` timed moves); -1 = the bench batch, 0 = skip")
     args = ap.parse_args()
 
     import torch
@@ -193,17 +204,27 @@ def main():
         ctx.load_weights(netspec.pack_blob(spec, weights))
     comm = None
     if world > 1:
+        # The product's transport or nothing: RCCL through the C ABI.  A failure ends the job with a non-zero exit (the
+        # launcher then stops the other ranks); a hang inside ncclCommInitRank / ncclBroadcast is not an exception, so a
+        # watchdog ends the process if the set-up has not finished in time.  No other transport is ever substituted: a
+        # scaling number over torch.distributed would not measure what DESIGN.md §7 describes.
+        import threading
+
+        def _give_up():
+            print(f"[bench] rank {rank}: RCCL set-up (mz_comm_init / mz_broadcast_weights) did not finish within "
+                  f"{args.comm_timeout} s", file=sys.stderr, flush=True)
+            os._exit(4)
+
+        dog = threading.Timer(args.comm_timeout, _give_up)
+        dog.daemon = True
+        dog.start()
         try:
             comm = mzd.NativeComm(ctx, rank, world)
             comm.broadcast_weights(0)
-        except Exception as e:   # noqa: BLE001 - keep the scaling run alive and say what carried the collectives
-            print(f"[bench] native RCCL communicator failed on rank {rank}: {e}; falling back to torch.distributed",
-                  file=sys.stderr, flush=True)
-            comm = mzd.HostComm("nccl", dev)
-            wt = comm.blob_tensor(spec, weights)
-            comm.broadcast_weights(wt, root=0)
-            torch.cuda.synchronize()
-            ctx.load_weights(wt)
+        except Exception as e:   # noqa: BLE001
+            print(f"[bench] rank {rank}: native RCCL communicator failed: {e}", file=sys.stderr, flush=True)
+            os._exit(3)
+        dog.cancel()
 
     # synthetic games: random 0/1 planes of density 0.3, all actions legal, device Gumbel noise
     gen = torch.Generator(device=dev)
@@ -313,8 +334,11 @@ def main():
                              "peak_GBps": 8000.0},
             "kernel_ms": {k: round(v, 3) for k, v in kernel_ms.items()},
         }
-        if args.fp32_games > 0 and world == 1 and args.precision != "fp32":
-            line["fp32_path"] = fp32_leg(spec, weights, n, m, c_visit, bounds, min(args.fp32_games, B), obs, local_rank)
+        if args.fp32_games != 0 and world == 1 and args.precision != "fp32":
+            ctx.close()   # its 35 GB hidden-state pool is not needed any more
+            ctx = None
+            fg = B if args.fp32_games < 0 else min(args.fp32_games, B)
+            line["fp32_path"] = fp32_leg(spec, weights, n, m, c_visit, bounds, fg, obs, local_rank, max(args.steps, 3))
         if not args.no_cpu_baseline and world == 1:   # timed beside the GPU at N = 1 only
             w_cpu = weights if weights is not None else netspec.random_weights(spec, seed=1)
             v, sims, secs, threads = cpu_baseline(spec, w_cpu, n, m, c_visit, bounds, args.cpu_games, seed=1000)
@@ -324,7 +348,8 @@ def main():
         print(json.dumps(line), flush=True)
     if comm is not None:
         comm.close()
-    ctx.close()
+    if ctx is not None:
+        ctx.close()
 
 
 if __name__ == "__main__":

@@ -57,7 +57,9 @@ typedef struct mz_search_config {
     /* withGumbel=true with the noise drawn ON THE DEVICE (GumbelFunctions.drawGumble, GumbelFunctions.java:48-54;
      * GumbelSearch.gumbelActionsStart, GumbelSearch.java:126-151): when device_gumbel != 0 and mz_search_moves gets
      * gumbel == NULL, k_root draws g = -log(-log(u)) per legal child from Philox4x32-10 keyed by gumbel_seed and
-     * counted by (move counter, game, action).  device_gumbel == 0 keeps NULL = withGumbel=false. */
+     * counted by (move counter, game, action).  device_gumbel == 0 keeps NULL = withGumbel=false.
+     * The game index is the index inside THIS context's batch: contexts that shard one set of games over several GPUs
+     * must be given different seeds (bench.py: 7 + 1000003 * rank), or shard r's game g repeats shard 0's noise. */
     uint64_t gumbel_seed;
     int32_t device_gumbel;
     int32_t reserved0;
@@ -126,7 +128,9 @@ int mz_commit_weights(mz_ctx* ctx);
  *                       host channel (file, socket, JVM-side rendezvous).
  *   mz_comm_init        ncclCommInitRank on the context's device; collective: every rank calls it.
  *   mz_broadcast_weights  ncclBroadcast of the fp32 master blob (mz_weights_device_ptr) from `root`, in place,
- *                       then the local repack of mz_commit_weights.  The root must have loaded its weights.
+ *                       then the local repack of mz_commit_weights on every rank (the root included, so a root that
+ *                       filled the master blob through mz_weights_device_ptr runs what it sent).  The root must have
+ *                       loaded or written its weights before.
  *   mz_gather_stats     ncclAllGather of n doubles per rank: out[r*n + i] = rank r's in[i] (host or device pointers).
  *   mz_comm_barrier     all ranks have reached this call and their streams have drained. */
 #define MZ_COMM_ID_BYTES 128
@@ -179,7 +183,8 @@ int mz_search_moves_injected(mz_ctx* ctx, int B, const uint8_t* legal, const uin
 
 /* Record the network outputs mz_search_moves uses, so a CPU replay can check the search bit for bit.
  * After a recorded call of B games: init_* [B*A] / [B], sim_* [B*S*A] / [B*S] with S = max_simulations and B = the
- * B of that recorded call (mz_get_recording copies exactly that many games; *B_out, if not NULL, receives it). */
+ * B of that recorded call: mz_get_recording copies exactly that many games, and mz_get_recording_games returns that B
+ * (0 when nothing is recorded or recording is switched off). */
 int mz_set_recording(mz_ctx* ctx, int enable);
 int mz_get_recording(mz_ctx* ctx, float* init_logits, float* init_policy, double* init_value, float* sim_logits,
                      float* sim_policy, double* sim_value);
@@ -232,7 +237,8 @@ const char* mz_version(void);
  * but every byte of scratch (trees, per-game state, step buffers) comes from one file-scope __device__ array of
  * MZ_NOALLOC_SCRATCH_BYTES that each GPU holds until the process ends; the call makes no hipMalloc / hipFree /
  * event creation and does not synchronize (work is queued on the context's stream: mz_synchronize afterwards).
- *  - every data pointer (inputs and outputs) must be DEVICE memory: host buffers would need staging allocations;
+ *  - every data pointer (inputs and outputs) must be memory OF THE CONTEXT'S DEVICE (or managed memory): host buffers
+ *    would need staging allocations, and a peer GPU's buffer is refused;
  *  - B, S and the action space must fit: mz_noalloc_scratch_bytes(ctx, B) <= MZ_NOALLOC_SCRATCH_BYTES, else error;
  *  - the array is shared by all calls on that GPU and keeps the last call's contents (the call clears what must
  *    start at zero); calls that overlap on one GPU (two contexts, two streams) race: serialise them;

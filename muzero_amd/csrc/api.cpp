@@ -142,6 +142,19 @@ int ctx_fail(mz_ctx* ctx, const std::string& msg) {
     return -1;
 }
 
+// Device (or managed) memory that device `dev` can address as its own: -1 = any device.
+bool is_device_ptr_on(const void* p, int dev) {
+    if (!p) return false;
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // clear
+        return false;
+    }
+    if (attr.type == hipMemoryTypeManaged) return true;
+    return attr.type == hipMemoryTypeDevice && (dev < 0 || attr.device == dev);
+}
+
 bool is_device_ptr(const void* p) {
     if (!p) return false;
     hipPointerAttribute_t attr;
@@ -692,7 +705,14 @@ int search_impl(mz_ctx* ctx, int B, const float* obs, const uint8_t* legal, cons
                 io.logits = ctx->net_logits + (size_t)g0 * A;
                 io.policy = ctx->net_policy + (size_t)g0 * A;
                 io.value = ctx->net_value + g0;
-                if (run_net(ctx, false, io, st)) return -1;
+                if (run_net(ctx, false, io, st)) {
+                    // leave no work of the second stream un-joined: later calls on ctx->stream reuse the same buffers
+                    if (nhalves == 2) {
+                        (void)hipStreamSynchronize(ctx->stream_b);
+                        (void)hipStreamSynchronize(ctx->stream);
+                    }
+                    return -1;
+                }
             }
             {
                 TimerScope ts(ctx, MZ_T_TREE_BACKUP, st);
@@ -1025,7 +1045,8 @@ int mz_broadcast_weights(mz_ctx* ctx, int root) {
     NCCL_TRY(rccl()->Broadcast(ctx->w_master, ctx->w_master, ctx->n_params, ncclFloat32, root, (ncclComm_t)ctx->comm,
                                ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    if (ctx->comm_rank == root) return 0;   // the root's packed copies already match its blob
+    // every rank repacks, the root too: a root that wrote the master blob through mz_weights_device_ptr without
+    // mz_commit_weights would otherwise broadcast weights it does not itself run
     return mz_commit_weights(ctx);
 }
 
@@ -1234,7 +1255,8 @@ int mz_search_moves_injected_noalloc(mz_ctx* ctx, int B, const uint8_t* legal, c
                           o.legal_action_max_entropy, o.root_entropy_value_target, o.playout_policy, o.playout_appended,
                           o.sims_run, o.status};
     for (const void* p : ptrs)
-        if (p && !is_device_ptr(p)) return ctx_fail(ctx, "the no-alloc entry point takes device pointers only");
+        if (p && !is_device_ptr_on(p, ctx->device))
+            return ctx_fail(ctx, "the no-alloc entry point takes pointers to memory of the context's own device only");
     const int steps = num_simulations ? ctx->cfg.max_simulations : ctx->cfg.search.num_simulations;
     if (S < steps) return ctx_fail(ctx, "S (recorded simulations) smaller than the simulation budget");
 

@@ -4,7 +4,8 @@ gather of per-rank episode statistics - runs over RCCL THROUGH THE C ABI (mz_com
 mz_gather_stats, include/muzero_hip.h): `NativeComm`.  torch.distributed is used for one thing only, the
 rendezvous that hands rank 0's 128-byte RCCL id to the other ranks (the c10d store torchrun already runs).
 `HostComm` offers the same four operations over a torch.distributed process group (gloo): it is what the CPU
-tests run (no RCCL without a GPU) and the fallback bench.py reports if the native communicator cannot start.
+tests run (no RCCL without a GPU; tests/test_dist_gloo.py also drives NativeComm itself over a stand-in context whose
+collectives are HostComm's).  bench.py never substitutes it: if RCCL cannot start, the run fails.
 The reference itself is single-device (ModelController.java:121,136).
 """
 import os
@@ -44,14 +45,16 @@ class NativeComm:
     """RCCL over xGMI behind the C ABI: the communicator lives in the mz_ctx."""
     kind = "rccl (C ABI: mz_comm_init / mz_broadcast_weights / mz_gather_stats)"
 
-    def __init__(self, ctx, rank, world_size, store=None):
-        from . import capi
+    def __init__(self, ctx, rank, world_size, store=None, make_id=None):
+        """make_id: what rank 0 calls for the 128-byte id (default mz_comm_unique_id; the CPU tests pass a stand-in)."""
+        if make_id is None:
+            from . import capi
+            make_id = capi.comm_unique_id
         self.ctx, self.rank, self.world = ctx, rank, world_size
         if world_size > 1:
-            uid = exchange_unique_id(store if store is not None else rendezvous_store(rank, world_size), rank,
-                                     capi.comm_unique_id)
+            uid = exchange_unique_id(store if store is not None else rendezvous_store(rank, world_size), rank, make_id)
         else:
-            uid = capi.comm_unique_id()
+            uid = make_id()
         ctx.comm_init(uid, rank, world_size)
 
     def broadcast_weights(self, root=0):

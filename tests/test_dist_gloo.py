@@ -95,3 +95,83 @@ def test_unique_id_rendezvous_without_a_process_group():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res[0][1] == res[1][1] == bytes(range(128))
+
+
+class _StandInCtx:
+    """The mz_ctx methods NativeComm calls (capi.Context: comm_init / broadcast_weights / gather_stats / comm_barrier /
+    comm_destroy), carried by HostComm's gloo collectives instead of RCCL, with a log of the calls."""
+
+    def __init__(self, host, blob):
+        self.host, self.blob, self.calls, self.uid = host, blob, [], None
+
+    def comm_init(self, uid, rank, world):
+        self.calls.append(("comm_init", rank, world))
+        self.uid = bytes(uid)
+
+    def broadcast_weights(self, root):
+        self.calls.append(("broadcast_weights", root))
+        self.host.broadcast_weights(self.blob, root)
+
+    def gather_stats(self, values, world):
+        self.calls.append(("gather_stats", len(values), world))
+        return self.host.gather_stats(values)
+
+    def comm_barrier(self):
+        self.calls.append(("comm_barrier",))
+        self.host.barrier()
+
+    def comm_destroy(self):
+        self.calls.append(("comm_destroy",))
+
+
+def _native_worker(rank, world, port, port2, total_games, q):
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    host = mzd.HostComm("gloo", torch.device("cpu"))
+    spec = netspec.spec_tiny()
+    weights = netspec.random_weights(spec, seed=7) if rank == 0 else None
+    blob = host.blob_tensor(spec, weights)
+    if rank != 0:
+        blob.fill_(-1.0)
+    ctx = _StandInCtx(host, blob)
+    store = torch.distributed.TCPStore("127.0.0.1", port2, world, rank == 0)    # the launcher's store in bench.py
+    comm = mzd.NativeComm(ctx, rank, world, store=store, make_id=lambda: bytes(range(128)))
+    # the very sequence of bench.py's N > 1 branch
+    comm.broadcast_weights(0)
+    comm.barrier()
+    lo, hi = mzd.shard_range(total_games, rank, world)
+    tmax = comm.max_over_ranks(1.0 + rank)
+    stats = comm.gather_stats([hi - lo, (hi - lo) * 20, float(blob.double().sum())])
+    comm.close()
+    q.put((rank, stats.tolist(), tmax, ctx.calls, ctx.uid, comm.kind))
+    host.close()
+
+
+def test_native_comm_call_sequence_over_a_stand_in_context():
+    """NativeComm (what bench.py runs for N > 1, over RCCL through the C ABI on a GPU box) driven at world size 2 over a
+    stand-in context: the id reaches every rank, the calls arrive in the order the C ABI expects (init, broadcast,
+    barrier, gathers, destroy), and its results equal HostComm's for the same worker body."""
+    world, total = 2, 101
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port, port2 = _free_port(), _free_port()
+    procs = [ctx.Process(target=_native_worker, args=(r, world, port, port2, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, st0, t0, calls0, uid0, kind0), (r1, st1, t1, calls1, uid1, kind1) = res
+    assert uid0 == uid1 == bytes(range(128))
+    want = [("comm_init", None, 2), ("broadcast_weights", 0), ("comm_barrier",), ("gather_stats", 1, 2),
+            ("gather_stats", 3, 2), ("comm_destroy",)]
+    for rank, calls in ((0, calls0), (1, calls1)):
+        assert [c[0] for c in calls] == [w[0] for w in want]
+        assert calls[0] == ("comm_init", rank, 2) and calls[1] == ("broadcast_weights", 0)
+    assert kind0 == kind1 and kind0.startswith("rccl (C ABI")           # what bench.py prints as config.collectives
+    assert st0 == st1 and t0 == t1 == 2.0
+    st = np.array(st0)
+    assert st[:, 0].sum() == total and st[0, 2] == st[1, 2]
+    ref = netspec.pack_blob(netspec.spec_tiny(), netspec.random_weights(netspec.spec_tiny(), seed=7))
+    assert abs(st[0, 2] - ref.astype(np.float64).sum()) < 1e-3

@@ -163,3 +163,40 @@ def test_other_network_shape_is_refused(tmp_path):
     src2 = tmp_path / "short.bin"
     blob[:-3].tofile(src2)
     assert "floats" in _tool("write", "tictactoe", src2, tmp_path, "m", 1, ok=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("game", ["go9", "tictactoe"])
+def test_checkpoint_through_the_device_matches_the_direct_blob(game, tmp_path):
+    """N2 end to end (still PARITY UNPINNED against DJL itself): blob -> saveDjlParams -> loadDjlParams -> mz_load_weights ->
+    mz_initial_inference / mz_recurrent_inference gives the outputs of the direct blob bit for bit, on the fp32 path and on
+    the default fp16-operand path (whose weight packing re-orders and scales every tensor).  Block order of the
+    checkpoint: Network.java:96-100."""
+    from muzero_amd import capi
+    from tests import helpers as H
+    spec = netspec.SPECS[game]()
+    blob = netspec.pack_blob(spec, netspec.random_weights(spec, seed=11, ln_jitter=0.2))
+    src, back = tmp_path / "blob.bin", tmp_path / "back.bin"
+    blob.tofile(src)
+    path = _tool("write", game, src, tmp_path, "MuZero-" + game, 3)
+    _tool("read", game, path, back)
+    loaded = np.fromfile(back, np.float32)
+    rng = np.random.default_rng(4)
+    B = 7
+    obs = H.synthetic_obs(rng, spec, B)
+    act = rng.integers(0, spec.action_space, B).astype(np.int32)
+    s0 = np.arange(B, dtype=np.int32)
+    for prec in (capi.PRECISION_FP32, capi.PRECISION_F16):
+        outs = []
+        for wts in (blob, loaded):
+            ctx = capi.Context(capi.make_config(spec, 4, 2, 50, max_games=B, precision=prec, pool_slots=2 * B))
+            ctx.load_weights(wts)
+            ctx.set_action_cells(netspec.action_cells_board(spec))
+            o0 = ctx.initial_inference(obs, s0)
+            o1 = ctx.recurrent_inference(s0, act, s0 + B)
+            hid = np.stack([ctx.read_hidden(s) for s in s0 + B])
+            outs.append([*o0, *o1, hid])
+            ctx.close()
+        for a, b in zip(*outs):
+            assert np.asarray(a).tobytes() == np.asarray(b).tobytes()
+        assert np.isfinite(outs[0][0]).all()

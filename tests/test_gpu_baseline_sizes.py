@@ -1,5 +1,5 @@
 """-m gpu: BASELINE.json's other workloads at their full batch (TicTacToe, PegSolitair and
-Go 5x5 at 4096 concurrent games, real bf16 nets, one planned move) - the shape of test_bench_size_properties_go9_bf16.
+Go 5x5 at 4096 concurrent games, real bf16 nets, one planned move) - the shape of test_bench_size_properties_go9.
 The oracle cannot replay 4096 x n forwards in seconds, so these check what holds at any size: budget identities,
 legality, normalisation, value range, and that games are independent units - the first k games searched alone
 (k a multiple of the boards per workgroup tile, so every game keeps its place in its tile) give bit-identical results.

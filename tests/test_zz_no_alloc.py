@@ -84,7 +84,7 @@ def test_noalloc_entry_point_rejects_what_it_cannot_serve():
                                           gumbel=t["g"])
     fits = 16
     assert ctx.noalloc_scratch_bytes(fits) <= capi.NOALLOC_SCRATCH_BYTES
-    with pytest.raises(capi.MuZeroError, match="device pointers only"):   # a host buffer would need staging
+    with pytest.raises(capi.MuZeroError, match="own device only"):   # a host buffer would need staging
         ctx.search_moves_injected_noalloc(fits, x["legal"][:fits].copy(), t["il"], t["ip"], t["iv"], t["sl"], t["sp"],
                                           t["sv"], n, outs, gumbel=t["g"])
     ctx.search_moves_injected_noalloc(fits, t["legal"], t["il"], t["ip"], t["iv"], t["sl"], t["sp"], t["sv"], n, outs,

@@ -18,6 +18,11 @@ def err(a, r):
     return float(np.max(np.abs(a - r) / (1.0 + np.abs(r))))
 
 
+def sq(a, r):   # (sum of squares, count) of the same quantity: for the rms the error model of netspec.error_model predicts
+    e = np.abs(a - r) / (1.0 + np.abs(r))
+    return np.array([float(np.sum(e.astype(np.float64) ** 2)), float(e.size)])
+
+
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 9000
@@ -25,6 +30,7 @@ def main():
     specs = T._specs()
     names = ["tictactoe", "go5", "go9", "pegsolitair"]
     worst = {n: dict(h=0.0, l=0.0, p=0.0, v=0.0) for n in names}
+    acc = {n: dict(h=np.zeros(2), l=np.zeros(2), p=np.zeros(2), v=np.zeros(2)) for n in names}
     rng0 = np.random.default_rng(seed0)
     for i in range(cases):
         name = names[i % 4]
@@ -51,13 +57,16 @@ def main():
         wv = worst[name]
         for a, r, k in ((hid, rs, "h"), (hid2, rs2, "h"), (lg, rl, "l"), (lg2, rl2, "l"), (pol, rp, "p"), (pol2, rp2, "p")):
             wv[k] = max(wv[k], err(a, r.numpy()))
+            acc[name][k] += sq(a, r.numpy())
         for a, r in ((val, rv), (val2, rv2)):
             wv["v"] = max(wv["v"], err(a / spec.value_scale, r.numpy() / spec.value_scale))
+            acc[name]["v"] += sq(a / spec.value_scale, r.numpy() / spec.value_scale)
         ctx.close()
         if i % 20 == 19:
             print(i + 1, "cases", flush=True)
     for n in names:
-        print(n, " ".join(f"{k}={v:.2e}" for k, v in worst[n].items()))
+        print(n, "max", " ".join(f"{k}={v:.2e}" for k, v in worst[n].items()),
+              "| rms", " ".join(f"{k}={np.sqrt(v[0] / max(v[1], 1)):.2e}" for k, v in acc[n].items()))
 
 
 if __name__ == "__main__":
