@@ -61,9 +61,9 @@ def _specs():
     }
 
 
-def _check(spec, precision, B, seed, ln_jitter=0.1):
+def _check(spec, precision, B, seed, ln_jitter=0.1, weights=None):
     rng = np.random.default_rng(seed)
-    w = netspec.random_weights(spec, seed=seed, ln_jitter=ln_jitter)
+    w = weights if weights is not None else netspec.random_weights(spec, seed=seed, ln_jitter=ln_jitter)
     blob = netspec.pack_blob(spec, w)
     cells = netspec.action_cells_board(spec)
     ctx = capi.Context(capi.make_config(spec, 4, 2, 50, max_games=B, precision=precision, pool_slots=2 * B))
@@ -140,6 +140,37 @@ def test_bf16_mfma_forward_matches_oracle(name):
 @pytest.mark.parametrize("name", ["go9", "pegsolitair", "tictactoe", "go5"])
 def test_f16_mfma_forward_matches_oracle(name):
     _check(_specs()[name], capi.PRECISION_F16, B=7, seed=3)
+
+
+def _scaled_affine(spec, seed, gain, shift):
+    w = netspec.random_weights(spec, seed=seed, ln_jitter=0.1)
+    for name in w:
+        if ".ln" in name and name.split(".")[0] in ("rep", "dyn"):
+            if name.endswith(".g"):
+                w[name] = (w[name] * gain).astype(np.float32)
+            elif name.endswith(".b"):
+                w[name] = (w[name] + shift).astype(np.float32)
+    return w
+
+
+@pytest.mark.parametrize("name", ["go9", "tictactoe"])
+def test_f16_large_layernorm_affine_takes_a_larger_activation_scale(name):
+    """The fp16 path stores gamma / S and beta / S and clamps to [0, 1] as its ReLU (net_mfma.hip: ln_apply_pk, ln_scale): S is
+    256 for the usual affine and grows with it.  gamma x 6, beta + 2 (S = 1024) must meet the same bars."""
+    spec = _specs()[name]
+    _check(spec, capi.PRECISION_F16, B=7, seed=21, weights=_scaled_affine(spec, 21, 6.0, 2.0))
+
+
+def test_f16_refuses_an_affine_its_scaled_activations_cannot_hold():
+    spec = _specs()["go9"]
+    blob = netspec.pack_blob(spec, _scaled_affine(spec, 22, 300.0, 0.0))
+    ctx = capi.Context(capi.make_config(spec, 4, 2, 50, max_games=2, precision=capi.PRECISION_F16, pool_slots=4))
+    with pytest.raises(capi.MuZeroError, match="too large for the fp16-operand path"):
+        ctx.load_weights(blob)
+    ctx.close()
+    ctx = capi.Context(capi.make_config(spec, 4, 2, 50, max_games=2, precision=capi.PRECISION_BF16, pool_slots=4))
+    ctx.load_weights(blob)      # the bf16 path has no such limit
+    ctx.close()
 
 
 @pytest.mark.parametrize("env,name", [({"MZ_FUSE": "0"}, "go9"), ({"MZ_FUSE": "1"}, "go9"),
