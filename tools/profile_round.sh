@@ -17,7 +17,16 @@ cp $(find $OUT/split -name '*kernel_stats.csv' | head -1) $OUT/bench_kernel_stat
 cp $(find $OUT/serial -name '*kernel_stats.csv' | head -1) $OUT/bench_serial_kernel_stats.csv
 rm -rf $OUT/split $OUT/serial
 bash $R/tools/pmc.sh $1 16384 go9 f16 > $OUT/pmc.log 2>&1
+# the bench lines below quote roofline.traffic from THIS measurement (bench.py:find_traffic takes the newest profiles/*traffic*)
+cp $R/gpurun_out/pmc_$1/traffic_go9_16384.json $R/profiles/$1_traffic_go9_16384.json
+cp $R/gpurun_out/pmc_$1/traffic_go9_16384.json $OUT/$1_traffic_go9_16384.json
 echo pmc done
+# the exact-fp32 path (the reference's own arithmetic) as the whole bench: kernel stats for k_net_fp32
+cd /tmp
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/fp32 -- python3 $R/bench.py --precision fp32 --fp32-games 0 --no-cpu-baseline > $OUT/bench_fp32_under_rocprof.log 2>&1
+cp $(find $OUT/fp32 -name '*kernel_stats.csv' | head -1) $OUT/fp32_kernel_stats.csv
+rm -rf $OUT/fp32
+echo fp32 done
 cd $R
 for wl in tictactoe go5 pegsolitair; do
   timeout -k 10 300 python3 bench.py --workload $wl --games 4096 --no-cpu-baseline --fp32-games 0 > $OUT/bench_$wl.log 2>&1
