@@ -203,7 +203,9 @@ def main():
     if weights is not None:
         ctx.load_weights(netspec.pack_blob(spec, weights))
     comm = None
-    if world > 1:
+    # MZ_BENCH_FORCE_COMM=1: take the N > 1 branch at world size 1 too (a rehearsal of the rendezvous, mz_comm_init,
+    # mz_broadcast_weights, mz_comm_barrier and mz_gather_stats calls on a one-GPU box)
+    if world > 1 or os.environ.get("MZ_BENCH_FORCE_COMM") == "1":
         # The product's transport or nothing: RCCL through the C ABI.  A failure ends the job with a non-zero exit (the
         # launcher then stops the other ranks); a hang inside ncclCommInitRank / ncclBroadcast is not an exception, so a
         # watchdog ends the process if the set-up has not finished in time.  No other transport is ever substituted: a
