@@ -361,8 +361,8 @@ inline int pad4(int x) { return (x + 3) & ~3; }
 // v_mfma_f32_16x16x4_f32 in 4 KiB units (tap, row tile of 16 output channels, 64 input channels): unit[s4][lane][e] =
 // w[16 mt + lane % 16][4 (16 c16 + 4 s4 + e) + lane / 16][tap], zero beyond Cin, so that a lane's operands of 16 k-steps are
 // four 16-byte loads and a wave's load is 1 KiB contiguous.
-void pack_conv(std::vector<float>& dst, long long& off_out, const float* w, int Cout, int Cin, int taps, int HW = 1 << 30) {
-    if (fp32_conv_on_mfma(Cout, pad4(Cout), HW)) {
+void pack_conv(std::vector<float>& dst, long long& off_out, const float* w, int Cout, int Cin, int taps, bool q16 = false) {
+    if (fp32_conv_on_mfma(q16, Cout)) {
         while (dst.size() % 4) dst.push_back(0.f);
         const int nmt = Cout / 16, nc16 = (Cin + 63) / 64;
         off_out = (long long)dst.size();
@@ -388,6 +388,15 @@ void pack_conv(std::vector<float>& dst, long long& off_out, const float* w, int 
         for (int ci = 0; ci < Cin; ci++)
             for (int t = 0; t < taps; t++) o[((size_t)ci * taps + t) * cp + co] = w[((size_t)co * Cin + ci) * taps + t];
 }
+// LayerNorm gamma / beta [Cn][HW] in the order the fp32 kernel holds the activations (Q16, net.h) - elementwise operands
+void pack_affine(std::vector<float>& dst, long long& off_out, const float* w, int Cn, int HW, bool q16) {
+    while (dst.size() % 4) dst.push_back(0.f);
+    off_out = (long long)dst.size();
+    dst.resize(dst.size() + (size_t)Cn * HW);
+    float* o = dst.data() + off_out;
+    for (int c = 0; c < Cn; c++)
+        for (int p = 0; p < HW; p++) o[q16 ? fp32_q16_index(c, p, HW) : c * HW + p] = w[(size_t)c * HW + p];
+}
 void pack_copy(std::vector<float>& dst, long long& off_out, const float* w, size_t n) {
     // keep every tensor 16-byte aligned for float4 loads
     while (dst.size() % 4) dst.push_back(0.f);
@@ -406,44 +415,45 @@ void pack_transpose(std::vector<float>& dst, long long& off_out, const float* w,
 
 void pack_tower_f32(const NetDims& d, BlobWalker& bw, std::vector<float>& dst, TowerOff& t, int cin0) {
     const int C = d.C, Cb = d.Cb, HW = d.HW;
+    const bool q16 = fp32_q16(C, Cb, HW);
     t.cin0 = cin0;
     while (dst.size() % 4) dst.push_back(0.f);
-    pack_conv(dst, t.conv0, bw.take((size_t)C * cin0 * 9), C, cin0, 9, HW);
+    pack_conv(dst, t.conv0, bw.take((size_t)C * cin0 * 9), C, cin0, 9, q16);
     for (int i = 0; i < d.R; i++) {
         BlockOff& b = t.blocks[i];
         std::memset(&b, 0, sizeof(b));
         bool bc = d.bcast_every_n > 0 && (i % d.bcast_every_n == d.bcast_every_n - 1);
         b.type = bc ? 1 : 0;
         if (!bc) {
-            pack_copy(dst, b.ln1g, bw.take((size_t)C * HW), (size_t)C * HW);
-            pack_copy(dst, b.ln1b, bw.take((size_t)C * HW), (size_t)C * HW);
+            pack_affine(dst, b.ln1g, bw.take((size_t)C * HW), C, HW, q16);
+            pack_affine(dst, b.ln1b, bw.take((size_t)C * HW), C, HW, q16);
             while (dst.size() % 4) dst.push_back(0.f);
-            pack_conv(dst, b.c1, bw.take((size_t)Cb * C), Cb, C, 1, HW);
-            pack_copy(dst, b.ln2g, bw.take((size_t)Cb * HW), (size_t)Cb * HW);
-            pack_copy(dst, b.ln2b, bw.take((size_t)Cb * HW), (size_t)Cb * HW);
+            pack_conv(dst, b.c1, bw.take((size_t)Cb * C), Cb, C, 1, q16);
+            pack_affine(dst, b.ln2g, bw.take((size_t)Cb * HW), Cb, HW, q16);
+            pack_affine(dst, b.ln2b, bw.take((size_t)Cb * HW), Cb, HW, q16);
             while (dst.size() % 4) dst.push_back(0.f);
-            pack_conv(dst, b.c2, bw.take((size_t)Cb * Cb * 9), Cb, Cb, 9, HW);
-            pack_copy(dst, b.ln3g, bw.take((size_t)Cb * HW), (size_t)Cb * HW);
-            pack_copy(dst, b.ln3b, bw.take((size_t)Cb * HW), (size_t)Cb * HW);
+            pack_conv(dst, b.c2, bw.take((size_t)Cb * Cb * 9), Cb, Cb, 9, q16);
+            pack_affine(dst, b.ln3g, bw.take((size_t)Cb * HW), Cb, HW, q16);
+            pack_affine(dst, b.ln3b, bw.take((size_t)Cb * HW), Cb, HW, q16);
             while (dst.size() % 4) dst.push_back(0.f);
-            pack_conv(dst, b.c3, bw.take((size_t)Cb * Cb * 9), Cb, Cb, 9, HW);
-            pack_copy(dst, b.ln4g, bw.take((size_t)Cb * HW), (size_t)Cb * HW);
-            pack_copy(dst, b.ln4b, bw.take((size_t)Cb * HW), (size_t)Cb * HW);
+            pack_conv(dst, b.c3, bw.take((size_t)Cb * Cb * 9), Cb, Cb, 9, q16);
+            pack_affine(dst, b.ln4g, bw.take((size_t)Cb * HW), Cb, HW, q16);
+            pack_affine(dst, b.ln4b, bw.take((size_t)Cb * HW), Cb, HW, q16);
             while (dst.size() % 4) dst.push_back(0.f);
-            pack_conv(dst, b.c4, bw.take((size_t)C * Cb), C, Cb, 1, HW);
+            pack_conv(dst, b.c4, bw.take((size_t)C * Cb), C, Cb, 1, q16);
         } else {
-            pack_copy(dst, b.ln1g, bw.take((size_t)C * HW), (size_t)C * HW);
-            pack_copy(dst, b.ln1b, bw.take((size_t)C * HW), (size_t)C * HW);
+            pack_affine(dst, b.ln1g, bw.take((size_t)C * HW), C, HW, q16);
+            pack_affine(dst, b.ln1b, bw.take((size_t)C * HW), C, HW, q16);
             while (dst.size() % 4) dst.push_back(0.f);
-            pack_conv(dst, b.c1, bw.take((size_t)C * C), C, C, 1, HW);
-            pack_copy(dst, b.ln2g, bw.take((size_t)C * HW), (size_t)C * HW);
-            pack_copy(dst, b.ln2b, bw.take((size_t)C * HW), (size_t)C * HW);
+            pack_conv(dst, b.c1, bw.take((size_t)C * C), C, C, 1, q16);
+            pack_affine(dst, b.ln2g, bw.take((size_t)C * HW), C, HW, q16);
+            pack_affine(dst, b.ln2b, bw.take((size_t)C * HW), C, HW, q16);
             pack_transpose(dst, b.bw, bw.take((size_t)HW * HW), HW, HW);  // W[q][p] -> Wt[p][q]
             pack_copy(dst, b.bb, bw.take((size_t)HW), (size_t)HW);
-            pack_copy(dst, b.ln3g, bw.take((size_t)C * HW), (size_t)C * HW);
-            pack_copy(dst, b.ln3b, bw.take((size_t)C * HW), (size_t)C * HW);
+            pack_affine(dst, b.ln3g, bw.take((size_t)C * HW), C, HW, q16);
+            pack_affine(dst, b.ln3b, bw.take((size_t)C * HW), C, HW, q16);
             while (dst.size() % 4) dst.push_back(0.f);
-            pack_conv(dst, b.c2, bw.take((size_t)C * C), C, C, 1, HW);
+            pack_conv(dst, b.c2, bw.take((size_t)C * C), C, C, 1, q16);
         }
     }
 }
@@ -1192,6 +1202,15 @@ int mz_read_hidden(mz_ctx* ctx, int32_t slot, float* out) {
         HIP_TRY(hipMemcpy(q.data(), ctx->pool + (size_t)(base + slot) * n, n * sizeof(float), hipMemcpyDefault));
         for (int ch = 0; ch < ctx->nd.C; ch++)
             for (int p = 0; p < HW; p++) r[(size_t)ch * HW + p] = q[((size_t)(ch / 4) * HW + p) * 4 + ch % 4];
+        HIP_TRY(hipMemcpy(out, r.data(), n * sizeof(float), hipMemcpyDefault));
+        return 0;
+    }
+    if (fp32_q16(ctx->nd.C, ctx->nd.Cb, ctx->nd.HW)) {   // the fp32 kernel's Q16 order (net.h)
+        const int HW = ctx->nd.HW;
+        std::vector<float> q(n), r(n);
+        HIP_TRY(hipMemcpy(q.data(), ctx->pool + (size_t)(base + slot) * n, n * sizeof(float), hipMemcpyDefault));
+        for (int ch = 0; ch < ctx->nd.C; ch++)
+            for (int p = 0; p < HW; p++) r[(size_t)ch * HW + p] = q[fp32_q16_index(ch, p, HW)];
         HIP_TRY(hipMemcpy(out, r.data(), n * sizeof(float), hipMemcpyDefault));
         return 0;
     }

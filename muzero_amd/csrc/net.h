@@ -34,7 +34,7 @@ struct NetProgramF32 {
     int c_pad, cb_pad;  // channel counts rounded up to a multiple of 4
 };
 
-// Batch I/O of one inference launch.  Hidden states are fp32 slots of C*HW floats in `pool`: [C][HW] on the fp32 path,
+// Batch I/O of one inference launch.  Hidden states are fp32 slots of C*HW floats in `pool`: Q16 order (above; [C][HW] for toy shapes) on the fp32 path,
 // [C/4][HW][4] (channel quads interleaved) on the MFMA path; mz_read_hidden always returns [C][H][W].
 struct NetIO {
     const float* obs;         // initial: [B][O][HW]
@@ -57,8 +57,16 @@ struct NetIO {
 void lds_optin(const void* fn);
 hipError_t take_optin_error();
 
+// The fp32 kernel keeps the activations of a network whose channel counts are multiples of 16 in the "Q16" order
+//     index(c, p) = (((c / 16) * 4 + c % 4) * HW + p) * 4 + (c / 4) % 4        [c/16][c%4][cell][(c/4)%4]
+// so that the B operands of four consecutive k-steps of v_mfma_f32_16x16x4_f32 (lane (cell, kq) of k-step 4G + s takes channel
+// 16G + 4s + kq) are ONE 16-byte LDS read; hidden-state slots of the fp32 path are stored in that order too (mz_read_hidden
+// un-permutes), and the LayerNorm gamma / beta tables are packed in it.  Other networks (toy shapes of the tests) stay in
+// [c][cell] and run every conv on the vector ALU.
+__host__ __device__ inline bool fp32_q16(int C, int Cb, int HW) { return (C & 15) == 0 && (Cb & 15) == 0 && HW <= 96; }
+__host__ __device__ inline int fp32_q16_index(int c, int p, int HW) { return ((((c >> 4) << 2) + (c & 3)) * HW + p) * 4 + ((c >> 2) & 3); }
 // true: k_net_fp32 runs this conv on v_mfma_f32_16x16x4_f32 and expects its weights in A-operand units (api.cpp:pack_conv)
-__host__ __device__ inline bool fp32_conv_on_mfma(int Cout, int CoutPad, int HW) { return (Cout & 15) == 0 && CoutPad == Cout && HW <= 96; }
+__host__ __device__ inline bool fp32_conv_on_mfma(bool q16, int Cout) { return q16 && (Cout & 15) == 0; }
 size_t fp32_lds_bytes(const NetDims& d);
 hipError_t launch_net_fp32(hipStream_t st, bool initial, const NetDims& d, const NetProgramF32* prog_dev,
                            const float* wbuf, const NetIO& io);

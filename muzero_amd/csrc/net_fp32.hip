@@ -144,9 +144,10 @@ __device__ __forceinline__ void ln_relu(const float* in, float* out, int n, cons
     __syncthreads();
 }
 
-// out[co][p] (+)= sum_ci sum_tap in[ci][nb(p,tap)] * Wt[ci][tap][co]   (Wt: co contiguous, padded to 4)
+// out[co][p] (+)= sum_ci sum_tap in[ci][nb(p,tap)] * Wt[ci][tap][co]   (Wt: co contiguous, padded to 4); `inq`: the input is
+// in Q16 order (net.h) - the head convs of a network whose tower runs on the matrix cores; the output is always [co][p]
 __device__ __forceinline__ void conv_valu(const float* in, float* out, const float* __restrict__ Wt, int Cin, int CoutPad, int Cout,
-                          int taps, const short* nb, int HW, bool accumulate) {
+                          int taps, const short* nb, int HW, bool accumulate, bool inq) {
     const int nco4 = CoutPad >> 2;
     const int items = nco4 * HW;
     for (int it = threadIdx.x; it < items; it += NT) {
@@ -156,7 +157,7 @@ __device__ __forceinline__ void conv_valu(const float* in, float* out, const flo
         if (taps == 1) {
             const float* w = Wt + co4 * 4;
             for (int ci = 0; ci < Cin; ci++) {
-                const float x = in[ci * HW + p];
+                const float x = in[inq ? fp32_q16_index(ci, p, HW) : ci * HW + p];
                 const float4 wv = *reinterpret_cast<const float4*>(w + (long long)ci * CoutPad);
                 acc.x = fmaf(x, wv.x, acc.x);
                 acc.y = fmaf(x, wv.y, acc.y);
@@ -169,11 +170,10 @@ __device__ __forceinline__ void conv_valu(const float* in, float* out, const flo
             for (int t = 0; t < 9; t++) q[t] = nb[t * HW + p];
             const float* w = Wt + co4 * 4;
             for (int ci = 0; ci < Cin; ci++) {
-                const float* row = in + ci * HW;
 #pragma unroll
                 for (int t = 0; t < 9; t++) {
                     if (q[t] >= 0) {
-                        const float x = row[q[t]];
+                        const float x = in[inq ? fp32_q16_index(ci, q[t], HW) : ci * HW + q[t]];
                         const float4 wv = *reinterpret_cast<const float4*>(w + (long long)(ci * 9 + t) * CoutPad);
                         acc.x = fmaf(x, wv.x, acc.x);
                         acc.y = fmaf(x, wv.y, acc.y);
@@ -197,29 +197,40 @@ __device__ __forceinline__ void conv_valu(const float* in, float* out, const flo
 }
 
 // The same conv on the matrix cores, exact fp32: v_mfma_f32_16x16x4_f32, D[out-ch][cell] += W[out-ch][k] * in[k][cell].
-// A wave owns MT adjacent row tiles of 16 output channels and all (<= 6) column tiles of 16 cells; K runs tap-major
+// A wave owns MT adjacent row tiles of 16 output channels and NTW (<= 6) column tiles of 16 cells; K runs tap-major
 // (the tap is wave-uniform, so the neighbour cell of a lane's column is looked up once per tap), four input channels
-// per MFMA, one per 16-lane group.  A operands: Wt[ci][tap][co] straight from global/L2 (16 consecutive floats per lane
-// group), requested a chunk of CH k-steps ahead; B operands: one ds_read_b32 per (k-step, column tile) from the [ch][HW]
-// image in LDS, 0 for off-board neighbours, padded columns and channels beyond Cin.
+// per MFMA, one per 16-lane group.  A operands: 4 KiB units of api.cpp:pack_conv straight from global/L2 (a lane's operands of
+// four k-steps are one 16-byte load), requested a chunk of CH k-steps ahead; B operands: the image is in Q16 order (net.h),
+// so a lane's operands of the four k-steps of a group of 16 input channels are ONE ds_read_b128; off-board neighbours and
+// padded columns read 16 zero bytes instead.  Input and output images are both Q16; Cin counts in whole groups of 16 (the
+// caller zero-fills the image up to there, the packed A operands are zero beyond Cin anyway).
 constexpr int MAXNT = 6;   // column tiles: HW <= 96
 extern __shared__ float lds_f32[];   // the kernel's dynamic LDS; the MFMA conv addresses it by offset so that its reads are ds_reads
 
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
 // A work item = MT adjacent row tiles x NTW column tiles starting at tile nt0 (a wave takes items wave, wave + NW, ...;
-// the column tiles are split in two when there are fewer row-tile groups than waves).  zero_off = an LDS word that holds 0.0f: off-board neighbours and padded
-// columns read it (address = ci * 0 + zero_off), so no B operand needs a select; channels beyond Cin read channel Cin - 1
-// against a zeroed A operand.  Loads are unconditional and their results pass through an empty asm statement before the
-// select: hipcc otherwise sinks a load under its condition and puts an EXEC-masked branch and a full s_waitcnt in front of
-// every MFMA.
+// the column tiles are split in two when there are fewer row-tile groups than waves).  zero_off = 16 LDS bytes that hold
+// 0.0f: off-board neighbours and padded columns read them (address = group * 0 + zero_off), so no B operand needs a select.
+// The arguments are wave-uniform but arrive in VGPRs (conv_lds is out of line): readfirstlane puts them back into SGPRs, so
+// that the loop control is scalar branches and not EXEC masks.
 template <int MT, int NTW>
 __device__ __forceinline__ void conv_mfma(int in_off, int out_off, const float* __restrict__ Wt, int Cin, int Cout, int taps,
                                           int nb_off, int zero_off, int HW, bool accumulate, int nsplit) {
     constexpr int CH = 16 / MT;                 // k-steps per chunk: 16 A registers in use, 16 in flight
+    constexpr int NG = CH / 4;                  // groups of 16 input channels per chunk
+    in_off = uni(in_off), out_off = uni(out_off), Cin = uni(Cin), Cout = uni(Cout), taps = uni(taps), nb_off = uni(nb_off);
+    zero_off = uni(zero_off), HW = uni(HW), nsplit = uni(nsplit);
+    accumulate = uni((int)accumulate) != 0;
+    {
+        const unsigned long long w = reinterpret_cast<unsigned long long>(Wt);
+        Wt = reinterpret_cast<const float*>(((unsigned long long)(unsigned)uni((int)(w >> 32)) << 32) | (unsigned)uni((int)w));
+    }
     const short* nb = reinterpret_cast<const short*>(lds_f32 + nb_off);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = uni(threadIdx.x >> 6);
     const int jl = lane & 15, kq = lane >> 4;
     const int nmt = Cout >> 4;
-    const int KS = (Cin + 3) >> 2;              // k-steps per tap
+    const int KS = ((Cin + 15) >> 4) << 2;      // k-steps per tap: whole groups
     const int nc16 = (Cin + 63) >> 6;           // 4 KiB weight units per (tap, row tile): api.cpp:pack_conv
     const int ngroups = nmt / MT;
     for (int it = wave; it < ngroups * nsplit; it += NW) {
@@ -229,15 +240,15 @@ __device__ __forceinline__ void conv_mfma(int in_off, int out_off, const float* 
         for (int m = 0; m < MT; m++)
 #pragma unroll
             for (int nt = 0; nt < NTW; nt++) acc[m][nt] = (f32x4v){0.f, 0.f, 0.f, 0.f};
-        // (an explicit global pointer: in this out-of-line function Wt is a generic pointer, and a flat_load counts on
-        // lgkmcnt as well, so every wait for a B operand would also wait for the A chunk requested ahead)
+        // (an explicit global pointer: a flat_load counts on lgkmcnt as well, so every wait for a B operand would also
+        // wait for the A chunk requested ahead)
         typedef const __attribute__((address_space(1))) f32x4v* gptr_t;
         gptr_t wlane = (gptr_t)(Wt) + lane;
         // the chunk's A operands: CH / 4 sixteen-byte loads per row tile, each 1 KiB contiguous over the wave; channels beyond
         // Cin are zeros in the packed units
         auto load_a = [&](int t, int s0, float (&a)[CH][MT]) {
 #pragma unroll
-            for (int j = 0; j < CH / 4; j++) {
+            for (int j = 0; j < NG; j++) {
                 const int qd = (s0 >> 2) + j;
 #pragma unroll
                 for (int m = 0; m < MT; m++) {
@@ -249,8 +260,16 @@ __device__ __forceinline__ void conv_mfma(int in_off, int out_off, const float* 
         };
         float a0[CH][MT], a1[CH][MT];
         load_a(0, 0, a0);
-        int qoff[NTW], hwm[NTW];
+        int base[NTW], gstr[NTW];   // byte address of the lane's 16 bytes of group 0, bytes per group
         int t = 0, s0 = 0;
+        auto read_b = [&](int G, int nt) -> f32x4v {   // v_mad_u32_u24 + ds_read_b128
+#if defined(MZ_X_NOB)   // experiment: no B traffic
+            const float z = (float)(G + base[nt]);
+            return (f32x4v){z, z, z, z};
+#else
+            return *reinterpret_cast<const f32x4v*>(reinterpret_cast<const char*>(lds_f32) + (__umul24(G, gstr[nt]) + base[nt]));
+#endif
+        };
         // one chunk: request the next chunk's A operands into `an`, run this chunk's MFMAs from `a`; returns false after the last
         // (a third set, two chunks in flight, measured 7 % slower)
         auto chunk = [&](float (&a)[CH][MT], float (&an)[CH][MT]) -> bool {
@@ -260,36 +279,51 @@ __device__ __forceinline__ void conv_mfma(int in_off, int out_off, const float* 
                 tn = t + 1;
             }
             const bool more = tn < taps;
+#if defined(MZ_X_NOA)   // experiment: no A traffic after the first chunk
+            if (more && false) load_a(tn, sn, an);
+#else
             if (more) load_a(tn, sn, an);
+#endif
             if (s0 == 0) {
 #pragma unroll
                 for (int nt = 0; nt < NTW; nt++) {
                     const int p = 16 * (nt0 + nt) + jl;
                     const int q = p < HW ? (taps == 1 ? p : (int)nb[t * HW + p]) : -1;
-                    qoff[nt] = 4 * (q >= 0 ? in_off + q : zero_off);   // byte address of channel 0
-                    hwm[nt] = q >= 0 ? 4 * HW : 0;                     // bytes per channel
+                    base[nt] = q >= 0 ? 4 * in_off + 16 * (kq * HW + q) : 4 * zero_off;
+                    gstr[nt] = q >= 0 ? 64 * HW : 0;
                 }
             }
+            const int G0 = s0 >> 2;
+            if (s0 + CH <= KS) {                          // a whole chunk: every read ahead of the first MFMA
+                f32x4v bv[NG][NTW];
 #pragma unroll
-            for (int g4 = 0; g4 < CH; g4 += 4) {          // groups of four k-steps; a group beyond the tap's last step is skipped
-                if (s0 + g4 < KS) {
-                    float bv[4][NTW];
+                for (int g = 0; g < NG; g++)
 #pragma unroll
-                    for (int s = 0; s < 4; s++) {
-                        int ci = 4 * (s0 + g4 + s) + kq;
-                        ci = ci < Cin ? ci : Cin - 1;
+                    for (int nt = 0; nt < NTW; nt++) bv[g][nt] = read_b(G0 + g, nt);
 #pragma unroll
-                        for (int nt = 0; nt < NTW; nt++)   // v_mad_u32_u24: one full-rate instruction per address
-                            bv[s][nt] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds_f32) +
-                                                                        (__umul24(ci, hwm[nt]) + qoff[nt]));
-                    }
+                for (int g = 0; g < NG; g++)
 #pragma unroll
                     for (int s = 0; s < 4; s++)
 #pragma unroll
                         for (int nt = 0; nt < NTW; nt++)
 #pragma unroll
                             for (int m = 0; m < MT; m++)
-                                acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g4 + s][m], bv[s][nt], acc[m][nt], 0, 0, 0);
+                                acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * g + s][m], bv[g][nt][s], acc[m][nt], 0, 0, 0);
+            } else {                                       // the tap's last chunk ends early: groups beyond KS are skipped
+#pragma unroll
+                for (int g = 0; g < NG; g++) {
+                    if (s0 + 4 * g < KS) {
+                        f32x4v bv[NTW];
+#pragma unroll
+                        for (int nt = 0; nt < NTW; nt++) bv[nt] = read_b(G0 + g, nt);
+#pragma unroll
+                        for (int s = 0; s < 4; s++)
+#pragma unroll
+                            for (int nt = 0; nt < NTW; nt++)
+#pragma unroll
+                                for (int m = 0; m < MT; m++)
+                                    acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * g + s][m], bv[nt][s], acc[m][nt], 0, 0, 0);
+                    }
                 }
             }
             if (!more) return false;
@@ -299,6 +333,7 @@ __device__ __forceinline__ void conv_mfma(int in_off, int out_off, const float* 
         };
         while (chunk(a0, a1) && chunk(a1, a0)) {
         }
+        // D[16 (mt0 + m) + 4 kq + r][cell] -> Q16: the wave's 64 lanes write 64 consecutive words per (m, nt, r)
 #pragma unroll
         for (int m = 0; m < MT; m++)
 #pragma unroll
@@ -306,7 +341,7 @@ __device__ __forceinline__ void conv_mfma(int in_off, int out_off, const float* 
                 if (16 * (nt0 + nt) + jl < HW) {
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
-                        float* o = lds_f32 + out_off + (16 * (mt0 + m) + 4 * kq + r) * HW + 16 * (nt0 + nt) + jl;
+                        float* o = lds_f32 + out_off + (((mt0 + m) * 4 + r) * HW + 16 * (nt0 + nt) + jl) * 4 + kq;
                         *o = accumulate ? (*o + acc[m][nt][r]) : acc[m][nt][r];
                     }
                 }
@@ -329,18 +364,21 @@ __device__ __forceinline__ void conv_mfma_nt(int in_off, int out_off, const floa
     }
 }
 
-// Convs whose output channels fill whole 16-row tiles go to the matrix cores; the rest (the head convs with 1 and 2
-// output channels, toy networks) stay on the vector ALU.
-__device__ __noinline__ void conv_lds(const float* in, float* out, const float* __restrict__ Wt, int Cin, int CoutPad, int Cout, int taps,
-                         const short* nb, int HW, bool accumulate) {
-    if (fp32_conv_on_mfma(Cout, CoutPad, HW)) {
+// offset (floats from the neighbour table) of the 16 zero bytes behind it
+__device__ __forceinline__ int zero_floats(int HW) { return ((9 * HW + 1) / 2 + 3) & ~3; }
+
+// The convs of a Q16 network (net.h) whose output channels fill whole 16-row tiles go to the matrix cores; the rest (the
+// head convs with 1 and 2 output channels, toy networks) stay on the vector ALU.
+__device__ __forceinline__ void conv_lds(const float* in, float* out, const float* __restrict__ Wt, int Cin, int CoutPad, int Cout, int taps,
+                         const short* nb, int HW, bool accumulate, bool q16) {
+    if (fp32_conv_on_mfma(q16, Cout)) {
         const int io = (int)(in - lds_f32), oo = (int)(out - lds_f32);
         const int no = (int)(reinterpret_cast<const float*>(nb) - lds_f32);
-        const int zo = no + (9 * HW + 1) / 2;   // the zero word behind the neighbour table (k_net_fp32 clears it)
+        const int zo = no + zero_floats(HW);   // k_net_fp32 clears them
         if ((Cout & 31) == 0 && Cout >= 128) conv_mfma_nt<2>(io, oo, Wt, Cin, Cout, taps, no, zo, HW, accumulate);
         else conv_mfma_nt<1>(io, oo, Wt, Cin, Cout, taps, no, zo, HW, accumulate);
     } else {
-        conv_valu(in, out, Wt, Cin, CoutPad, Cout, taps, nb, HW, accumulate);
+        conv_valu(in, out, Wt, Cin, CoutPad, Cout, taps, nb, HW, accumulate, q16);
     }
 }
 
@@ -362,16 +400,18 @@ __device__ __forceinline__ void broadcast_lds(const float* in, float* out, const
 #define TC(x) { long long t_ = __builtin_amdgcn_s_memtime(); x; tconv += __builtin_amdgcn_s_memtime() - t_; }
 #define TL(x) { long long t_ = __builtin_amdgcn_s_memtime(); x; tln += __builtin_amdgcn_s_memtime() - t_; }
 #define TB(x) { long long t_ = __builtin_amdgcn_s_memtime(); x; tbc += __builtin_amdgcn_s_memtime() - t_; }
+#define TH(x) { long long t_ = __builtin_amdgcn_s_memtime(); x; thd += __builtin_amdgcn_s_memtime() - t_; }
 #else
 #define TC(x) x
 #define TL(x) x
 #define TB(x) x
+#define TH(x) x
 #endif
 // BroadcastBlock on the matrix cores: D[q][c] = sum_p Wt[p][q] * in[c][p] (+ b[q]): row tiles over the output cells q, column
 // tiles over the channels (a wave takes channel tiles wave, wave + NW, ...), four cells p per MFMA.
 template <int NTQ>
 __device__ __forceinline__ void broadcast_mfma(int in_off, int out_off, const float* __restrict__ Wt, const float* __restrict__ b,
-                                               int C, int HW) {
+                                               int C, int HW, bool q16) {
     typedef const __attribute__((address_space(1))) float* gptr_t;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int jl = lane & 15, kq = lane >> 4;
@@ -381,12 +421,12 @@ __device__ __forceinline__ void broadcast_mfma(int in_off, int out_off, const fl
         f32x4v acc[NTQ];
 #pragma unroll
         for (int mt = 0; mt < NTQ; mt++) acc[mt] = (f32x4v){0.f, 0.f, 0.f, 0.f};
-        const int crow = in_off + (16 * ct + jl) * HW;
+        const int ch = 16 * ct + jl;
         for (int ks = 0; ks < KS; ks++) {
             const int p = 4 * ks + kq;
             const bool pok = p < HW;
             const int pc = pok ? p : HW - 1;
-            float bvl = lds_f32[crow + pc];
+            float bvl = lds_f32[in_off + (q16 ? fp32_q16_index(ch, pc, HW) : ch * HW + pc)];
             float av[NTQ];
 #pragma unroll
             for (int mt = 0; mt < NTQ; mt++) {
@@ -403,22 +443,22 @@ __device__ __forceinline__ void broadcast_mfma(int in_off, int out_off, const fl
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int q = 16 * mt + 4 * kq + r;
-                if (q < HW) lds_f32[out_off + (16 * ct + jl) * HW + q] = acc[mt][r] + b[q];
+                if (q < HW) lds_f32[out_off + (q16 ? fp32_q16_index(ch, q, HW) : ch * HW + q)] = acc[mt][r] + b[q];
             }
     }
     __syncthreads();
 }
-__device__ __noinline__ void broadcast_any(const float* in, float* out, const float* __restrict__ Wt, const float* __restrict__ b,
-                                           int C, int HW) {
+__device__ __forceinline__ void broadcast_any(const float* in, float* out, const float* __restrict__ Wt, const float* __restrict__ b,
+                                           int C, int HW, bool q16) {
     const int io = (int)(in - lds_f32), oo = (int)(out - lds_f32);
-    if ((C & 15) == 0 && HW <= 16 * MAXNT) {
+    if (q16 || ((C & 15) == 0 && HW <= 16 * MAXNT)) {
         switch ((HW + 15) >> 4) {
-            case 1: broadcast_mfma<1>(io, oo, Wt, b, C, HW); break;
-            case 2: broadcast_mfma<2>(io, oo, Wt, b, C, HW); break;
-            case 3: broadcast_mfma<3>(io, oo, Wt, b, C, HW); break;
-            case 4: broadcast_mfma<4>(io, oo, Wt, b, C, HW); break;
-            case 5: broadcast_mfma<5>(io, oo, Wt, b, C, HW); break;
-            default: broadcast_mfma<6>(io, oo, Wt, b, C, HW); break;
+            case 1: broadcast_mfma<1>(io, oo, Wt, b, C, HW, q16); break;
+            case 2: broadcast_mfma<2>(io, oo, Wt, b, C, HW, q16); break;
+            case 3: broadcast_mfma<3>(io, oo, Wt, b, C, HW, q16); break;
+            case 4: broadcast_mfma<4>(io, oo, Wt, b, C, HW, q16); break;
+            case 5: broadcast_mfma<5>(io, oo, Wt, b, C, HW, q16); break;
+            default: broadcast_mfma<6>(io, oo, Wt, b, C, HW, q16); break;
         }
     } else {
         broadcast_lds(in, out, Wt, b, C, HW);
@@ -431,7 +471,7 @@ __global__ __launch_bounds__(NT) void k_net_fp32(NetDims d, const NetProgramF32*
     float* smem = lds_f32;
     const int g = blockIdx.x;
 #if defined(MZ_FP32_STAMPS)
-    long long tconv = 0, tln = 0, tbc = 0;
+    long long tconv = 0, tln = 0, tbc = 0, thd = 0;
     const long long tstart = __builtin_amdgcn_s_memtime();
 #endif
     if (io.active && !io.active[g]) return;
@@ -443,47 +483,94 @@ __global__ __launch_bounds__(NT) void k_net_fp32(NetDims d, const NetProgramF32*
     short* nb = reinterpret_cast<short*>(red + 8);
     const int tid = threadIdx.x;
     const int c_pad = prog->c_pad, cb_pad = prog->cb_pad;
+    const bool q16 = fp32_q16(C, Cb, HW);   // activations, hidden-state slots and gamma / beta in Q16 order (net.h)
 
     for (int i = tid; i < 9 * HW; i += NT) {
         const int t = i / HW, p = i - t * HW;
         const int y = p / d.Wd + t / 3 - 1, x = p % d.Wd + t % 3 - 1;
         nb[i] = (y >= 0 && y < d.H && x >= 0 && x < d.Wd) ? (short)(y * d.Wd + x) : (short)-1;
     }
-    if (tid == 0) reinterpret_cast<float*>(nb)[(9 * HW + 1) / 2] = 0.f;   // what off-board taps of the MFMA convs read
+    if (tid < 4) reinterpret_cast<float*>(nb)[zero_floats(HW) + tid] = 0.f;   // what off-board taps of the MFMA convs read
     const TowerOff& tw = INITIAL ? prog->rep : prog->dyn;
+    // element j of a Q16 image -> its channel and cell
+    auto unq16 = [&](int j, int& c, int& p) {
+        const int G = j / (16 * HW), r = j - G * 16 * HW, c4 = r / (4 * HW), r2 = r - c4 * 4 * HW;
+        p = r2 >> 2;
+        c = 16 * G + 4 * (r2 & 3) + c4;
+    };
     if (INITIAL) {
         const float* src = io.obs + (long long)g * d.O * HW;
-        for (int i = tid; i < d.O * HW; i += NT) T1[i] = src[i];
+        if (q16) {   // the observation planes, zero-filled to whole groups of 16 channels
+            for (int j = tid; j < ((d.O + 15) & ~15) * HW; j += NT) {
+                int c, p;
+                unq16(j, c, p);
+                T1[j] = c < d.O ? src[c * HW + p] : 0.f;
+            }
+        } else {
+            for (int i = tid; i < d.O * HW; i += NT) T1[i] = src[i];
+        }
     } else {
         const float* src = io.pool + (long long)io.src_slot[g] * C * HW;
         for (int i = tid; i < C * HW; i += NT) T1[i] = src[i];
         const int cell = io.action_cells[io.action[g]];
-        for (int i = tid; i < d.a * HW; i += NT) T1[C * HW + i] = (i == cell) ? 1.f : 0.f;  // ConcatInputsBlock
+        if (q16) {   // ConcatInputsBlock: the action planes are channels C .. C + a - 1 of group C / 16
+            for (int j = tid; j < ((d.a + 15) & ~15) * HW; j += NT) {
+                int c, p;
+                unq16(j, c, p);
+                T1[C * HW + j] = (c < d.a && c * HW + p == cell) ? 1.f : 0.f;
+            }
+        } else {
+            for (int i = tid; i < d.a * HW; i += NT) T1[C * HW + i] = (i == cell) ? 1.f : 0.f;  // ConcatInputsBlock
+        }
     }
     __syncthreads();
-    TC(conv_lds(T1, X, wb + tw.conv0, tw.cin0, c_pad, C, 9, nb, HW, false);)
-    if (!INITIAL) {  // StartResidualBlock: conv3x3(cat[s, a]) + s
-        for (int i = tid; i < C * HW; i += NT) X[i] += T1[i];
-        __syncthreads();
-    }
-    for (int r = 0; r < d.R; r++) {
-        const BlockOff& b = tw.blocks[r];
-        if (b.type == 0) {
-            TL(ln_relu(X, T1, C * HW, wb + b.ln1g, wb + b.ln1b, red);)
-            TC(conv_lds(T1, T2, wb + b.c1, C, cb_pad, Cb, 1, nb, HW, false);)
-            TL(ln_relu(T2, T2, Cb * HW, wb + b.ln2g, wb + b.ln2b, red);)
-            TC(conv_lds(T2, T1, wb + b.c2, Cb, cb_pad, Cb, 9, nb, HW, false);)
-            TL(ln_relu(T1, T1, Cb * HW, wb + b.ln3g, wb + b.ln3b, red);)
-            TC(conv_lds(T1, T2, wb + b.c3, Cb, cb_pad, Cb, 9, nb, HW, false);)
-            TL(ln_relu(T2, T2, Cb * HW, wb + b.ln4g, wb + b.ln4b, red);)
-            TC(conv_lds(T2, X, wb + b.c4, Cb, c_pad, C, 1, nb, HW, true);)
-        } else {
-            TL(ln_relu(X, T1, C * HW, wb + b.ln1g, wb + b.ln1b, red);)
-            TC(conv_lds(T1, T2, wb + b.c1, C, c_pad, C, 1, nb, HW, false);)
-            TL(ln_relu(T2, T2, C * HW, wb + b.ln2g, wb + b.ln2b, red);)
-            TB(broadcast_any(T2, T1, wb + b.bw, wb + b.bb, C, HW);)
-            TL(ln_relu(T1, T1, C * HW, wb + b.ln3g, wb + b.ln3b, red);)
-            TC(conv_lds(T1, X, wb + b.c2, C, c_pad, C, 1, nb, HW, true);)
+    // The tower as a list of steps [LayerNorm + ReLU] -> [broadcast] -> [conv]: ONE inlined copy of each routine in a loop over
+    // the steps, their operands picked by wave-uniform selects.  (Out-of-line routines called from ten sites cost more than
+    // they saved: every call spilled and refilled ~100 callee-saved VGPRs per lane through scratch memory.)
+    // step (-1, 0) = the input conv; a bottleneck block = 4 steps, a broadcast block = 3.
+    const int oX = 0, oT1 = buf_floats, oT2 = 2 * buf_floats;
+    for (int r = -1; r < d.R; r++) {
+        const BlockOff& b = tw.blocks[r < 0 ? 0 : r];
+        const int btype = r < 0 ? -1 : b.type;
+        const int nj = btype < 0 ? 1 : (btype == 0 ? 4 : 3);
+        for (int j = 0; j < nj; j++) {
+            int ln_in = 0, ln_out = 0, ln_c = 0, cv_in = oT1, cv_out = oX, cv_cin = tw.cin0, cv_cout = C, cv_pad = c_pad, cv_taps = 9;
+            long long ln_g = 0, ln_b = 0, cv_w = tw.conv0;
+            bool do_conv = true, cv_acc = false;
+            if (btype == 0) {          // BottleneckResidualBlock.java:55-79
+                ln_in = j == 0 ? oX : (j == 2 ? oT1 : oT2);
+                ln_out = (j & 1) ? oT2 : oT1;
+                ln_c = j == 0 ? C : Cb;
+                ln_g = j == 0 ? b.ln1g : j == 1 ? b.ln2g : j == 2 ? b.ln3g : b.ln4g;
+                ln_b = j == 0 ? b.ln1b : j == 1 ? b.ln2b : j == 2 ? b.ln3b : b.ln4b;
+                cv_in = ln_out;
+                cv_out = j == 3 ? oX : ((j & 1) ? oT1 : oT2);
+                cv_cin = j == 0 ? C : Cb;
+                cv_cout = j == 3 ? C : Cb;
+                cv_pad = j == 3 ? c_pad : cb_pad;
+                cv_taps = (j == 1 || j == 2) ? 9 : 1;
+                cv_w = j == 0 ? b.c1 : j == 1 ? b.c2 : j == 2 ? b.c3 : b.c4;
+                cv_acc = j == 3;
+            } else if (btype == 1) {   // BroadcastResidualBlock.java:56-77
+                ln_in = j == 0 ? oX : (j == 1 ? oT2 : oT1);
+                ln_out = j == 1 ? oT2 : oT1;
+                ln_c = C;
+                ln_g = j == 0 ? b.ln1g : j == 1 ? b.ln2g : b.ln3g;
+                ln_b = j == 0 ? b.ln1b : j == 1 ? b.ln2b : b.ln3b;
+                do_conv = j != 1;
+                cv_in = oT1;
+                cv_out = j == 0 ? oT2 : oX;
+                cv_cin = C, cv_cout = C, cv_pad = c_pad, cv_taps = 1;
+                cv_w = j == 0 ? b.c1 : b.c2;
+                cv_acc = j == 2;
+            }
+            if (btype >= 0) TL(ln_relu(smem + ln_in, smem + ln_out, ln_c * HW, wb + ln_g, wb + ln_b, red);)
+            if (btype == 1 && j == 1) TB(broadcast_any(T2, T1, wb + b.bw, wb + b.bb, C, HW, q16);)
+            if (do_conv) TC(conv_lds(smem + cv_in, smem + cv_out, wb + cv_w, cv_cin, cv_pad, cv_cout, cv_taps, nb, HW, cv_acc, q16);)
+            if (btype < 0 && !INITIAL) {  // StartResidualBlock: conv3x3(cat[s, a]) + s
+                for (int i = tid; i < C * HW; i += NT) X[i] += T1[i];
+                __syncthreads();
+            }
         }
     }
     // RescaleBlockExt: (x - min) / max(max - min, 1e-5) over the whole sample
@@ -506,7 +593,7 @@ __global__ __launch_bounds__(NT) void k_net_fp32(NetDims d, const NetProgramF32*
     }
     // PredictionBlock
     const HeadOff& h = prog->head;
-    TC(conv_lds(X, T1, wb + h.pconv, C, 4, 2, 1, nb, HW, false);)
+    TH(conv_valu(X, T1, wb + h.pconv, C, 4, 2, 1, nb, HW, false, q16);)
     TL(ln_relu(T1, T1, 2 * HW, wb + h.plng, wb + h.plnb, red);)
     float* lgt = T2;  // logits staged in LDS for the softmax
     for (int a = tid; a < A; a += NT) {
@@ -528,7 +615,7 @@ __global__ __launch_bounds__(NT) void k_net_fp32(NetDims d, const NetProgramF32*
         }
         __syncthreads();
     }
-    TC(conv_lds(X, T1, wb + h.vconv, C, 4, 1, 1, nb, HW, false);)
+    TH(conv_valu(X, T1, wb + h.vconv, C, 4, 1, 1, nb, HW, false, q16);)
     TL(ln_relu(T1, T1, HW, wb + h.vlng, wb + h.vlnb, red);)
     float part = 0.f;
     for (int c = tid; c < C; c += NT) {
@@ -542,7 +629,7 @@ __global__ __launch_bounds__(NT) void k_net_fp32(NetDims d, const NetProgramF32*
     if (tid == 0) io.value[g] = d.value_scale * (double)v;
 #if defined(MZ_FP32_STAMPS)
     if (g == 0 && tid == 0)
-        printf("fp32 board: total %lld conv %lld ln %lld bcast %lld\n", (long long)__builtin_amdgcn_s_memtime() - tstart, tconv, tln, tbc);
+        printf("fp32 board: total %lld conv %lld ln %lld bcast %lld headconv %lld\n", (long long)__builtin_amdgcn_s_memtime() - tstart, tconv, tln, tbc, thd);
 #endif
 }
 
@@ -551,12 +638,16 @@ __global__ __launch_bounds__(NT) void k_net_fp32(NetDims d, const NetProgramF32*
 size_t fp32_buf_floats(const NetDims& d) {
     int extra = d.a > d.O ? d.a : d.O;
     size_t n = (size_t)(d.C + extra) * d.HW;
+    if (fp32_q16(d.C, d.Cb, d.HW)) {   // conv0's input image in whole groups of 16 channels
+        const size_t rec = (size_t)(d.C + ((d.a + 15) & ~15)) * d.HW, ini = (size_t)((d.O + 15) & ~15) * d.HW;
+        n = rec > ini ? rec : ini;
+    }
     size_t head = (size_t)(d.A > 2 * d.HW ? d.A : 2 * d.HW);
     return ((n > head ? n : head) + 3) & ~(size_t)3;   // 16-byte aligned buffers (float4 LayerNorm passes)
 }
 
 size_t fp32_lds_bytes(const NetDims& d) {
-    return (3 * fp32_buf_floats(d) + 8) * sizeof(float) + (size_t)9 * d.HW * sizeof(short) + 16;
+    return (3 * fp32_buf_floats(d) + 8) * sizeof(float) + (size_t)9 * d.HW * sizeof(short) + 48;   // + the 16 zero bytes
 }
 
 namespace {
