@@ -397,15 +397,15 @@ __device__ __forceinline__ void broadcast_lds(const float* in, float* out, const
 }
 
 #if defined(MZ_FP32_STAMPS)
-#define TC(x) { long long t_ = __builtin_amdgcn_s_memtime(); x; tconv += __builtin_amdgcn_s_memtime() - t_; }
-#define TL(x) { long long t_ = __builtin_amdgcn_s_memtime(); x; tln += __builtin_amdgcn_s_memtime() - t_; }
-#define TB(x) { long long t_ = __builtin_amdgcn_s_memtime(); x; tbc += __builtin_amdgcn_s_memtime() - t_; }
-#define TH(x) { long long t_ = __builtin_amdgcn_s_memtime(); x; thd += __builtin_amdgcn_s_memtime() - t_; }
+#define TC(...) { long long t_ = __builtin_amdgcn_s_memtime(); __VA_ARGS__; tconv += __builtin_amdgcn_s_memtime() - t_; }
+#define TL(...) { long long t_ = __builtin_amdgcn_s_memtime(); __VA_ARGS__; tln += __builtin_amdgcn_s_memtime() - t_; }
+#define TB(...) { long long t_ = __builtin_amdgcn_s_memtime(); __VA_ARGS__; tbc += __builtin_amdgcn_s_memtime() - t_; }
+#define TH(...) { long long t_ = __builtin_amdgcn_s_memtime(); __VA_ARGS__; thd += __builtin_amdgcn_s_memtime() - t_; }
 #else
-#define TC(x) x
-#define TL(x) x
-#define TB(x) x
-#define TH(x) x
+#define TC(...) __VA_ARGS__
+#define TL(...) __VA_ARGS__
+#define TB(...) __VA_ARGS__
+#define TH(...) __VA_ARGS__
 #endif
 // BroadcastBlock on the matrix cores: D[q][c] = sum_p Wt[p][q] * in[c][p] (+ b[q]): row tiles over the output cells q, column
 // tiles over the channels (a wave takes channel tiles wave, wave + NW, ...), four cells p per MFMA.
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(NT) void k_net_fp32(NetDims d, const NetProgramF32*
     float* smem = lds_f32;
     const int g = blockIdx.x;
 #if defined(MZ_FP32_STAMPS)
-    long long tconv = 0, tln = 0, tbc = 0, thd = 0;
+    long long tconv = 0, tln = 0, tbc = 0, thd = 0, tmark = 0, tstage = 0, trescale = 0, tfc = 0;
     const long long tstart = __builtin_amdgcn_s_memtime();
 #endif
     if (io.active && !io.active[g]) return;
@@ -511,7 +511,25 @@ __global__ __launch_bounds__(NT) void k_net_fp32(NetDims d, const NetProgramF32*
         }
     } else {
         const float* src = io.pool + (long long)io.src_slot[g] * C * HW;
-        for (int i = tid; i < C * HW; i += NT) T1[i] = src[i];
+        if (((C * HW) & 3) == 0) {   // the parent state: every load of a batch in flight before the first LDS store
+            const float4* src4 = reinterpret_cast<const float4*>(src);
+            const int n4 = (C * HW) >> 2;
+            for (int i0 = 0; i0 < n4; i0 += 6 * NT) {
+                float4 v[6];
+#pragma unroll
+                for (int j = 0; j < 6; j++) {
+                    const int i = i0 + tid + j * NT;
+                    v[j] = src4[i < n4 ? i : 0];
+                }
+#pragma unroll
+                for (int j = 0; j < 6; j++) {
+                    const int i = i0 + tid + j * NT;
+                    if (i < n4) reinterpret_cast<float4*>(T1)[i] = v[j];
+                }
+            }
+        } else {
+            for (int i = tid; i < C * HW; i += NT) T1[i] = src[i];
+        }
         const int cell = io.action_cells[io.action[g]];
         if (q16) {   // ConcatInputsBlock: the action planes are channels C .. C + a - 1 of group C / 16
             for (int j = tid; j < ((d.a + 15) & ~15) * HW; j += NT) {
@@ -524,6 +542,9 @@ __global__ __launch_bounds__(NT) void k_net_fp32(NetDims d, const NetProgramF32*
         }
     }
     __syncthreads();
+#if defined(MZ_FP32_STAMPS)
+    tstage = __builtin_amdgcn_s_memtime() - tstart;
+#endif
     // The tower as a list of steps [LayerNorm + ReLU] -> [broadcast] -> [conv]: ONE inlined copy of each routine in a loop over
     // the steps, their operands picked by wave-uniform selects.  (Out-of-line routines called from ten sites cost more than
     // they saved: every call spilled and refilled ~100 callee-saved VGPRs per lane through scratch memory.)
@@ -574,6 +595,9 @@ __global__ __launch_bounds__(NT) void k_net_fp32(NetDims d, const NetProgramF32*
         }
     }
     // RescaleBlockExt: (x - min) / max(max - min, 1e-5) over the whole sample
+#if defined(MZ_FP32_STAMPS)
+    tmark = __builtin_amdgcn_s_memtime();
+#endif
     {
         float mn = INFINITY, mx = -INFINITY;
         for (int i = tid; i < C * HW; i += NT) {
@@ -591,17 +615,66 @@ __global__ __launch_bounds__(NT) void k_net_fp32(NetDims d, const NetProgramF32*
         }
         __syncthreads();
     }
-    // PredictionBlock
+#if defined(MZ_FP32_STAMPS)
+    trescale = __builtin_amdgcn_s_memtime() - tmark;
+#endif
+    // PredictionBlock (PredictionBlock.java:46-84).  Both 1x1 head convs in one pass over X, then the two small LayerNorms,
+    // the policy and value linears.  Every reduction dimension is dealt over NPART groups of threads (partial sums in LDS,
+    // added in a fixed order): one thread per output would leave most of the 512 idle on chains of 128..162 dependent loads.
     const HeadOff& h = prog->head;
-    TH(conv_valu(X, T1, wb + h.pconv, C, 4, 2, 1, nb, HW, false, q16);)
-    TL(ln_relu(T1, T1, 2 * HW, wb + h.plng, wb + h.plnb, red);)
-    float* lgt = T2;  // logits staged in LDS for the softmax
-    for (int a = tid; a < A; a += NT) {
-        float acc = wb[h.pfcb + a];
-        for (int i = 0; i < 2 * HW; i++) acc = fmaf(T1[i], wb[h.pfcw + (long long)i * A + a], acc);
-        lgt[a] = acc;
+    float* pc = T1;              // policy conv -> LayerNorm -> [2][HW]
+    float* vc = T1 + 2 * HW;     // value conv -> LayerNorm -> [HW]
+    float* part_buf = T2;        // partial sums
+    {
+        const int np = max(1, min(min(NT / HW, buf_floats / (3 * HW)), C));   // buf_floats >= 3 HW (fp32_buf_floats)
+        TH(
+        for (int it = tid; it < np * HW; it += NT) {
+            const int part = it / HW, p = it - part * HW;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+            for (int c = part; c < C; c += np) {
+                const float x = X[q16 ? fp32_q16_index(c, p, HW) : c * HW + p];
+                const float4 wp = *reinterpret_cast<const float4*>(wb + h.pconv + (long long)c * 4);
+                const float wv = wb[h.vconv + (long long)c * 4];
+                a0 = fmaf(x, wp.x, a0);
+                a1 = fmaf(x, wp.y, a1);
+                a2 = fmaf(x, wv, a2);
+            }
+            part_buf[(part * 3 + 0) * HW + p] = a0;
+            part_buf[(part * 3 + 1) * HW + p] = a1;
+            part_buf[(part * 3 + 2) * HW + p] = a2;
+        }
+        __syncthreads();
+        for (int it = tid; it < 3 * HW; it += NT) {
+            float a = 0.f;
+            for (int part = 0; part < np; part++) a += part_buf[part * 3 * HW + it];
+            T1[it] = a;   // [p0 | p1 | v] = pc, vc
+        }
+        __syncthreads();
+        )
     }
-    __syncthreads();
+    TL(ln_relu(pc, pc, 2 * HW, wb + h.plng, wb + h.plnb, red);)
+    TL(ln_relu(vc, vc, HW, wb + h.vlng, wb + h.vlnb, red);)
+#if defined(MZ_FP32_STAMPS)
+    tmark = __builtin_amdgcn_s_memtime();
+#endif
+    float* lgt = T2;                 // logits staged in LDS for the softmax
+    float* fc_part = T2 + ((A + 3) & ~3);
+    {
+        const int np = max(1, min(min(NT / A, (buf_floats - ((A + 3) & ~3)) / A), 2 * HW));
+        for (int it = tid; it < np * A; it += NT) {
+            const int part = it / A, a = it - part * A;
+            float acc = 0.f;
+            for (int i = part; i < 2 * HW; i += np) acc = fmaf(pc[i], wb[h.pfcw + (long long)i * A + a], acc);
+            fc_part[it] = acc;
+        }
+        __syncthreads();
+        for (int a = tid; a < A; a += NT) {
+            float acc = wb[h.pfcb + a];
+            for (int part = 0; part < np; part++) acc += fc_part[part * A + a];
+            lgt[a] = acc;
+        }
+        __syncthreads();
+    }
     {
         float mx = -INFINITY;
         for (int a = tid; a < A; a += NT) mx = fmaxf(mx, lgt[a]);
@@ -615,21 +688,30 @@ __global__ __launch_bounds__(NT) void k_net_fp32(NetDims d, const NetProgramF32*
         }
         __syncthreads();
     }
-    TH(conv_valu(X, T1, wb + h.vconv, C, 4, 1, 1, nb, HW, false, q16);)
-    TL(ln_relu(T1, T1, HW, wb + h.vlng, wb + h.vlnb, red);)
     float part = 0.f;
-    for (int c = tid; c < C; c += NT) {
-        float acc = wb[h.vfc1b + c];
-        for (int p = 0; p < HW; p++) acc = fmaf(T1[p], wb[h.vfc1w + (long long)p * C + c], acc);
-        acc = acc > 0.f ? acc : 0.f;
-        part = fmaf(acc, wb[h.vfc2w + c], part);
+    {
+        const int np = max(1, min(min(NT / C, buf_floats / C), HW));
+        for (int it = tid; it < np * C; it += NT) {
+            const int pt = it / C, c = it - pt * C;
+            float acc = 0.f;
+            for (int p = pt; p < HW; p += np) acc = fmaf(vc[p], wb[h.vfc1w + (long long)p * C + c], acc);
+            part_buf[it] = acc;
+        }
+        __syncthreads();
+        for (int c = tid; c < C; c += NT) {
+            float acc = wb[h.vfc1b + c];
+            for (int pt = 0; pt < np; pt++) acc += part_buf[pt * C + c];
+            acc = acc > 0.f ? acc : 0.f;
+            part = fmaf(acc, wb[h.vfc2w + c], part);
+        }
     }
     float v = block_sum(part, red) + wb[h.vfc2b];
     if (d.two_players) v = tanhf(v);
     if (tid == 0) io.value[g] = d.value_scale * (double)v;
 #if defined(MZ_FP32_STAMPS)
     if (g == 0 && tid == 0)
-        printf("fp32 board: total %lld conv %lld ln %lld bcast %lld headconv %lld\n", (long long)__builtin_amdgcn_s_memtime() - tstart, tconv, tln, tbc, thd);
+        printf("fp32 board: total %lld conv %lld ln %lld bcast %lld headconv %lld staging %lld rescale %lld fc+softmax %lld\n",
+               (long long)__builtin_amdgcn_s_memtime() - tstart, tconv, tln, tbc, thd, tstage, trescale, (long long)__builtin_amdgcn_s_memtime() - tmark);
 #endif
 }
 
@@ -642,7 +724,9 @@ size_t fp32_buf_floats(const NetDims& d) {
         const size_t rec = (size_t)(d.C + ((d.a + 15) & ~15)) * d.HW, ini = (size_t)((d.O + 15) & ~15) * d.HW;
         n = rec > ini ? rec : ini;
     }
-    size_t head = (size_t)(d.A > 2 * d.HW ? d.A : 2 * d.HW);
+    const size_t a4 = ((size_t)d.A + 3) & ~(size_t)3;
+    size_t head = 2 * a4 > (size_t)3 * d.HW ? 2 * a4 : (size_t)3 * d.HW;   // the heads' staging: [3][HW] partial sums, logits + partials
+    if (head < (size_t)d.C) head = d.C;
     return ((n > head ? n : head) + 3) & ~(size_t)3;   // 16-byte aligned buffers (float4 LayerNorm passes)
 }
 

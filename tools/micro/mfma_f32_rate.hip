@@ -69,7 +69,10 @@ int main() {
     hipMalloc(&out, 256 * 1024 * 4);
     hipMalloc(&cyc, 8);
     for (int w : {1, 2, 4}) {
+        run<16, 2>(w, out, cyc);
+        run<16, 3>(w, out, cyc);
         run<16, 4>(w, out, cyc);
+        run<16, 6>(w, out, cyc);
         run<16, 8>(w, out, cyc);
         run<32, 2>(w, out, cyc);
         run<32, 4>(w, out, cyc);

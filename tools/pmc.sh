@@ -33,7 +33,7 @@ for i in (1, 2, 3, 4, 5, 6):
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
             disp[k].add(r["Dispatch_Id"])
     for k, v in sorted(agg.items()):
-        if any(t in k for t in ("k_seg", "k_bcast", "k_bseg", "k_tower", "k_heads")):
+        if any(t in k for t in ("k_seg", "k_bcast", "k_bseg", "k_tower", "k_heads", "k_net_fp32")):
             n = len(disp[k])
             print(f"{k:46s} dispatches {n:3d}  " + "  ".join(f"{a}={b / n:.4g}" for a, b in sorted(v.items())))
             # the recurrent chain only (IN_OBS kernels belong to the one initialInference that sets the states up)
