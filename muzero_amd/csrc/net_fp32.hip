@@ -21,7 +21,12 @@ namespace mz {
 
 namespace {
 
-constexpr int NT = 512;   // 8 waves, two per SIMD: the partner wave covers LDS / L2 latency of the MFMA convs
+#if defined(MZ_X_NT)   // experiment: waves per workgroup
+constexpr int NT = MZ_X_NT;
+#else
+constexpr int NT = 512;
+#endif
+//   // 8 waves, two per SIMD: the partner wave covers LDS / L2 latency of the MFMA convs
 constexpr int NW = NT / 64;
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
@@ -78,7 +83,7 @@ __device__ __forceinline__ void ln_relu(const float* in, float* out, int n, cons
     // Fast path (every tower LayerNorm: n = channels * HW with channels % 4 == 0, at most LNI float4 items per thread): the
     // thread's items are read once and stay in registers through both statistics passes and the normalisation, and its
     // gamma/beta entries are requested first, so their L2 round trip runs under the two block reductions.
-    constexpr int LNI = 6;
+    constexpr int LNI = 3072 / NT;
     const bool vec = (n & 3) == 0 && (n >> 2) <= LNI * NT &&
                      ((reinterpret_cast<size_t>(gamma) | reinterpret_cast<size_t>(beta) | reinterpret_cast<size_t>(in) |
                        reinterpret_cast<size_t>(out)) & 15) == 0;
@@ -353,7 +358,9 @@ template <int MT>
 __device__ __forceinline__ void conv_mfma_nt(int in_off, int out_off, const float* __restrict__ Wt, int Cin, int Cout, int taps,
                                              int nb_off, int zero_off, int HW, bool accumulate) {
     const int ntl = (HW + 15) >> 4;
-    const int nsplit = (ntl >= 2 && (Cout >> 4) / MT < NW) ? 2 : 1;
+    const int ngr = (Cout >> 4) / MT;
+    int nsplit = (NW + ngr - 1) / ngr;            // enough work items for every wave
+    nsplit = nsplit < 1 ? 1 : (nsplit > ntl ? ntl : nsplit);
     switch ((ntl + nsplit - 1) / nsplit) {
         case 1: conv_mfma<MT, 1>(in_off, out_off, Wt, Cin, Cout, taps, nb_off, zero_off, HW, accumulate, nsplit); break;
         case 2: conv_mfma<MT, 2>(in_off, out_off, Wt, Cin, Cout, taps, nb_off, zero_off, HW, accumulate, nsplit); break;

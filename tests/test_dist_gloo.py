@@ -21,6 +21,53 @@ def _free_port():
     return p
 
 
+def _guarded(body, rank, q, *args):
+    """Worker entry: an exception reaches the parent as text at once instead of as a 120 s queue timeout."""
+    try:
+        body(rank, *args, q)
+    except BaseException:
+        import traceback
+        q.put(("error", rank, traceback.format_exc()))
+        raise
+
+
+def _run_ranks(body, world, nports, *args):
+    """Spawn `world` ranks of body(rank, world, *ports, *args, q) and return their sorted results.  The ports come from
+    bind(0) and are released before the ranks bind them again, so another process can take one in between: a rendezvous
+    that fails that way (address in use / nobody answered) is tried once more on fresh ports; anything else fails."""
+    last = None
+    for attempt in range(2):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        ports = [_free_port() for _ in range(nports)]
+        procs = [ctx.Process(target=_guarded, args=(body, r, q, world, *ports, *args)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res, err = [], None
+        try:
+            for _ in range(world):
+                item = q.get(timeout=120)
+                if item and item[0] == "error":
+                    err = item[2]
+                    break
+                res.append(item)
+        except Exception as e:   # queue.Empty: a rank never answered
+            err = "no answer from a rank within 120 s: %r" % (e,)
+        for p in procs:
+            p.join(timeout=10 if err else 60)
+            if p.is_alive():
+                p.kill()
+                p.join()
+        if err is None:
+            assert all(p.exitcode == 0 for p in procs)
+            return sorted(res)
+        last = err
+        if not any(t in err for t in ("Address already in use", "EADDRINUSE", "no answer from a rank", "Connection refused",
+                                      "Connection reset")):
+            break
+    raise AssertionError("rank failed:\n" + last)
+
+
 def _worker(rank, world, port, total_games, q):
     os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
@@ -43,16 +90,7 @@ def _worker(rank, world, port, total_games, q):
 
 def test_two_rank_sharding_broadcast_and_gather():
     world, total = 2, 101
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = sorted(q.get(timeout=120) for _ in range(world))
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = _run_ranks(_worker, world, 1, total)
     (r0, lo0, hi0, st0, t0, b0), (r1, lo1, hi1, st1, t1, b1) = res
     assert (lo0, hi0, lo1, hi1) == (0, 51, 51, 101)       # contiguous, complete, no overlap
     assert st0 == st1                                     # every rank sees the same gathered table
@@ -83,17 +121,7 @@ def _id_worker(rank, world, port, q):
 
 
 def test_unique_id_rendezvous_without_a_process_group():
-    world = 2
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_id_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = sorted(q.get(timeout=120) for _ in range(world))
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = _run_ranks(_id_worker, 2, 1)
     assert res[0][1] == res[1][1] == bytes(range(128))
 
 
@@ -152,16 +180,7 @@ def test_native_comm_call_sequence_over_a_stand_in_context():
     stand-in context: the id reaches every rank, the calls arrive in the order the C ABI expects (init, broadcast,
     barrier, gathers, destroy), and its results equal HostComm's for the same worker body."""
     world, total = 2, 101
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port, port2 = _free_port(), _free_port()
-    procs = [ctx.Process(target=_native_worker, args=(r, world, port, port2, total, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = sorted(q.get(timeout=120) for _ in range(world))
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = _run_ranks(_native_worker, world, 2, total)
     (r0, st0, t0, calls0, uid0, kind0), (r1, st1, t1, calls1, uid1, kind1) = res
     assert uid0 == uid1 == bytes(range(128))
     want = [("comm_init", None, 2), ("broadcast_weights", 0), ("comm_barrier",), ("gather_stats", 1, 2),
