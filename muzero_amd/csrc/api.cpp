@@ -388,14 +388,16 @@ void pack_conv(std::vector<float>& dst, long long& off_out, const float* w, int 
         for (int ci = 0; ci < Cin; ci++)
             for (int t = 0; t < taps; t++) o[((size_t)ci * taps + t) * cp + co] = w[((size_t)co * Cin + ci) * taps + t];
 }
-// LayerNorm gamma / beta [Cn][HW] in the order the fp32 kernel holds the activations (Q16, net.h) - elementwise operands
+// LayerNorm gamma / beta [Cn][HW] in the order the fp32 kernel holds the activations in LDS (Q16 with planes of HW + 1 cells,
+// net.h: gamma = beta = 0 at the zero cell, which therefore stays zero) - elementwise operands
 void pack_affine(std::vector<float>& dst, long long& off_out, const float* w, int Cn, int HW, bool q16) {
     while (dst.size() % 4) dst.push_back(0.f);
     off_out = (long long)dst.size();
-    dst.resize(dst.size() + (size_t)Cn * HW);
+    const int hwp = q16 ? HW + 1 : HW;
+    dst.resize(dst.size() + (size_t)Cn * hwp, 0.f);
     float* o = dst.data() + off_out;
     for (int c = 0; c < Cn; c++)
-        for (int p = 0; p < HW; p++) o[q16 ? fp32_q16_index(c, p, HW) : c * HW + p] = w[(size_t)c * HW + p];
+        for (int p = 0; p < HW; p++) o[q16 ? fp32_q16_index(c, p, hwp) : c * HW + p] = w[(size_t)c * HW + p];
 }
 void pack_copy(std::vector<float>& dst, long long& off_out, const float* w, size_t n) {
     // keep every tensor 16-byte aligned for float4 loads

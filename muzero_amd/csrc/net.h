@@ -61,7 +61,8 @@ hipError_t take_optin_error();
 //     index(c, p) = (((c / 16) * 4 + c % 4) * HW + p) * 4 + (c / 4) % 4        [c/16][c%4][cell][(c/4)%4]
 // so that the B operands of four consecutive k-steps of v_mfma_f32_16x16x4_f32 (lane (cell, kq) of k-step 4G + s takes channel
 // 16G + 4s + kq) are ONE 16-byte LDS read; hidden-state slots of the fp32 path are stored in that order too (mz_read_hidden
-// un-permutes), and the LayerNorm gamma / beta tables are packed in it.  Other networks (toy shapes of the tests) stay in
+// un-permutes), and the LayerNorm gamma / beta tables are packed in it.  In LDS and in the gamma / beta tables a plane has
+// HW + 1 cells, the last one a zero cell (what the convs read for off-board taps); the slots have planes of HW cells.  Other networks (toy shapes of the tests) stay in
 // [c][cell] and run every conv on the vector ALU.
 __host__ __device__ inline bool fp32_q16(int C, int Cb, int HW) { return (C & 15) == 0 && (Cb & 15) == 0 && HW <= 96; }
 __host__ __device__ inline int fp32_q16_index(int c, int p, int HW) { return ((((c >> 4) << 2) + (c & 3)) * HW + p) * 4 + ((c >> 2) & 3); }

@@ -77,9 +77,13 @@ __device__ __forceinline__ float block_min(float v, float* red) {
     return r;
 }
 
-// LayerNorm over all n = channels*HW elements of one sample (eps 1e-5, affine [c][hw]) + ReLU.
+// LayerNorm over all channels*HW elements of one sample (eps 1e-5, affine [c][hw]) + ReLU.  n = the elements stored; hwp > 0:
+// a Q16 image (net.h) whose planes carry a zero cell behind the board (cell hwp - 1 of every hwp): those cells hold 0 and
+// have gamma = beta = 0, so they add nothing to the sum and come out as 0, but they are not samples: `count` = the real
+// element count, and the centred squares skip them (padmask: bit j = this thread's j-th float4 of the fast path is one).
 __device__ __forceinline__ void ln_relu(const float* in, float* out, int n, const float* __restrict__ gamma,
-                        const float* __restrict__ beta, float* red) {
+                        const float* __restrict__ beta, float* red, int count = 0, int hwp = 0, unsigned padmask = 0) {
+    if (count == 0) count = n;
     // Fast path (every tower LayerNorm: n = channels * HW with channels % 4 == 0, at most LNI float4 items per thread): the
     // thread's items are read once and stay in registers through both statistics passes and the normalisation, and its
     // gamma/beta entries are requested first, so their L2 round trip runs under the two block reductions.
@@ -107,15 +111,15 @@ __device__ __forceinline__ void ln_relu(const float* in, float* out, int n, cons
 #pragma unroll
         for (int j = 0; j < LNI; j++)
             if (threadIdx.x + j * NT < n4) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
-        const float mean = block_sum(s, red) / (float)n;
+        const float mean = block_sum(s, red) / (float)count;
         float q = 0.f;
 #pragma unroll
         for (int j = 0; j < LNI; j++)
-            if (threadIdx.x + j * NT < n4) {
+            if (threadIdx.x + j * NT < n4 && !((padmask >> j) & 1)) {
                 const float d0 = v[j].x - mean, d1 = v[j].y - mean, d2 = v[j].z - mean, d3 = v[j].w - mean;
                 q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
             }
-        const float var = block_sum(q, red) / (float)n;
+        const float var = block_sum(q, red) / (float)count;
         const float rstd = 1.0f / sqrtf(var + 1e-5f);
 #pragma unroll
         for (int j = 0; j < LNI; j++) {
@@ -134,13 +138,14 @@ __device__ __forceinline__ void ln_relu(const float* in, float* out, int n, cons
     }
     float s = 0.f;
     for (int i = threadIdx.x; i < n; i += NT) s += in[i];
-    const float mean = block_sum(s, red) / (float)n;
+    const float mean = block_sum(s, red) / (float)count;
     float q = 0.f;
     for (int i = threadIdx.x; i < n; i += NT) {
         float dlt = in[i] - mean;
+        if (hwp > 0 && (i >> 2) % hwp == hwp - 1) dlt = 0.f;
         q += dlt * dlt;
     }
-    const float var = block_sum(q, red) / (float)n;
+    const float var = block_sum(q, red) / (float)count;
     const float rstd = 1.0f / sqrtf(var + 1e-5f);
     for (int i = threadIdx.x; i < n; i += NT) {
         float y = (in[i] - mean) * rstd * gamma[i] + beta[i];
@@ -149,10 +154,9 @@ __device__ __forceinline__ void ln_relu(const float* in, float* out, int n, cons
     __syncthreads();
 }
 
-// out[co][p] (+)= sum_ci sum_tap in[ci][nb(p,tap)] * Wt[ci][tap][co]   (Wt: co contiguous, padded to 4); `inq`: the input is
-// in Q16 order (net.h) - the head convs of a network whose tower runs on the matrix cores; the output is always [co][p]
+// out[co][p] (+)= sum_ci sum_tap in[ci][nb(p,tap)] * Wt[ci][tap][co]   (Wt: co contiguous, padded to 4)
 __device__ __forceinline__ void conv_valu(const float* in, float* out, const float* __restrict__ Wt, int Cin, int CoutPad, int Cout,
-                          int taps, const short* nb, int HW, bool accumulate, bool inq) {
+                          int taps, const short* nb, int HW, bool accumulate) {
     const int nco4 = CoutPad >> 2;
     const int items = nco4 * HW;
     for (int it = threadIdx.x; it < items; it += NT) {
@@ -162,7 +166,7 @@ __device__ __forceinline__ void conv_valu(const float* in, float* out, const flo
         if (taps == 1) {
             const float* w = Wt + co4 * 4;
             for (int ci = 0; ci < Cin; ci++) {
-                const float x = in[inq ? fp32_q16_index(ci, p, HW) : ci * HW + p];
+                const float x = in[ci * HW + p];
                 const float4 wv = *reinterpret_cast<const float4*>(w + (long long)ci * CoutPad);
                 acc.x = fmaf(x, wv.x, acc.x);
                 acc.y = fmaf(x, wv.y, acc.y);
@@ -178,7 +182,7 @@ __device__ __forceinline__ void conv_valu(const float* in, float* out, const flo
 #pragma unroll
                 for (int t = 0; t < 9; t++) {
                     if (q[t] >= 0) {
-                        const float x = in[inq ? fp32_q16_index(ci, q[t], HW) : ci * HW + q[t]];
+                        const float x = in[ci * HW + q[t]];
                         const float4 wv = *reinterpret_cast<const float4*>(w + (long long)(ci * 9 + t) * CoutPad);
                         acc.x = fmaf(x, wv.x, acc.x);
                         acc.y = fmaf(x, wv.y, acc.y);
@@ -206,26 +210,30 @@ __device__ __forceinline__ void conv_valu(const float* in, float* out, const flo
 // (the tap is wave-uniform, so the neighbour cell of a lane's column is looked up once per tap), four input channels
 // per MFMA, one per 16-lane group.  A operands: 4 KiB units of api.cpp:pack_conv straight from global/L2 (a lane's operands of
 // four k-steps are one 16-byte load), requested a chunk of CH k-steps ahead; B operands: the image is in Q16 order (net.h),
-// so a lane's operands of the four k-steps of a group of 16 input channels are ONE ds_read_b128; off-board neighbours and
-// padded columns read 16 zero bytes instead.  Input and output images are both Q16; Cin counts in whole groups of 16 (the
-// caller zero-fills the image up to there, the packed A operands are zero beyond Cin anyway).
+// so a lane's operands of the four k-steps of a group of 16 input channels are ONE ds_read_b128.  Every plane of the image
+// carries a zero cell behind the board (planes of HWp = HW + 1 cells): the neighbour table names it for off-board taps and
+// for the padded columns of the last tile, so a B address is base + group * stride with no select anywhere - the loop has
+// ONE MFMA (32 cycles) of slack per wave, and every vector instruction between two MFMAs beyond that idles the matrix pipe
+// (tools/micro/f32_chunk.hip).  Input and output images are both Q16; Cin counts in whole groups of 16 (the caller
+// zero-fills the image up to there, the packed A operands are zero beyond Cin anyway).
 constexpr int MAXNT = 6;   // column tiles: HW <= 96
 extern __shared__ float lds_f32[];   // the kernel's dynamic LDS; the MFMA conv addresses it by offset so that its reads are ds_reads
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // A work item = MT adjacent row tiles x NTW column tiles starting at tile nt0 (a wave takes items wave, wave + NW, ...;
-// the column tiles are split in two when there are fewer row-tile groups than waves).  zero_off = 16 LDS bytes that hold
-// 0.0f: off-board neighbours and padded columns read them (address = group * 0 + zero_off), so no B operand needs a select.
-// The arguments are wave-uniform but arrive in VGPRs (conv_lds is out of line): readfirstlane puts them back into SGPRs, so
-// that the loop control is scalar branches and not EXEC masks.
+// the column tiles are split when there are fewer row-tile groups than waves).  nb = the neighbour table [tap][NP] of
+// k_net_fp32 (NP = 16 column tiles' worth of columns; row 4, the centre tap, serves the 1x1 convs).
+// readfirstlane keeps the wave-uniform arguments in SGPRs whatever the inliner does, so that the loop control is scalar
+// branches and not EXEC masks.
 template <int MT, int NTW>
 __device__ __forceinline__ void conv_mfma(int in_off, int out_off, const float* __restrict__ Wt, int Cin, int Cout, int taps,
-                                          int nb_off, int zero_off, int HW, bool accumulate, int nsplit) {
+                                          int nb_off, int NP, int HW, bool accumulate, int nsplit) {
     constexpr int CH = 16 / MT;                 // k-steps per chunk: 16 A registers in use, 16 in flight
     constexpr int NG = CH / 4;                  // groups of 16 input channels per chunk
     in_off = uni(in_off), out_off = uni(out_off), Cin = uni(Cin), Cout = uni(Cout), taps = uni(taps), nb_off = uni(nb_off);
-    zero_off = uni(zero_off), HW = uni(HW), nsplit = uni(nsplit);
+    NP = uni(NP), HW = uni(HW), nsplit = uni(nsplit);
+    const int HWp = HW + 1, gstride = 64 * HWp;   // cells per plane, bytes per group of 16 channels
     accumulate = uni((int)accumulate) != 0;
     {
         const unsigned long long w = reinterpret_cast<unsigned long long>(Wt);
@@ -265,14 +273,15 @@ __device__ __forceinline__ void conv_mfma(int in_off, int out_off, const float* 
         };
         float a0[CH][MT], a1[CH][MT];
         load_a(0, 0, a0);
-        int base[NTW], gstr[NTW];   // byte address of the lane's 16 bytes of group 0, bytes per group
+        int base[NTW];              // byte address of the lane's 16 bytes of group 0
+        const int cbase = 4 * in_off + 16 * kq * HWp;
         int t = 0, s0 = 0;
-        auto read_b = [&](int G, int nt) -> f32x4v {   // v_mad_u32_u24 + ds_read_b128
+        auto read_b = [&](int G, int nt) -> f32x4v {   // s_mul + v_add + ds_read_b128
 #if defined(MZ_X_NOB)   // experiment: no B traffic
             const float z = (float)(G + base[nt]);
             return (f32x4v){z, z, z, z};
 #else
-            return *reinterpret_cast<const f32x4v*>(reinterpret_cast<const char*>(lds_f32) + (__umul24(G, gstr[nt]) + base[nt]));
+            return *reinterpret_cast<const f32x4v*>(reinterpret_cast<const char*>(lds_f32) + (G * gstride + base[nt]));
 #endif
         };
         // one chunk: request the next chunk's A operands into `an`, run this chunk's MFMAs from `a`; returns false after the last
@@ -290,13 +299,9 @@ __device__ __forceinline__ void conv_mfma(int in_off, int out_off, const float* 
             if (more) load_a(tn, sn, an);
 #endif
             if (s0 == 0) {
+                const int trow = (taps == 1 ? 4 : t) * NP + 16 * nt0 + jl;
 #pragma unroll
-                for (int nt = 0; nt < NTW; nt++) {
-                    const int p = 16 * (nt0 + nt) + jl;
-                    const int q = p < HW ? (taps == 1 ? p : (int)nb[t * HW + p]) : -1;
-                    base[nt] = q >= 0 ? 4 * in_off + 16 * (kq * HW + q) : 4 * zero_off;
-                    gstr[nt] = q >= 0 ? 64 * HW : 0;
-                }
+                for (int nt = 0; nt < NTW; nt++) base[nt] = cbase + 16 * (int)nb[trow + 16 * nt];
             }
             const int G0 = s0 >> 2;
             if (s0 + CH <= KS) {                          // a whole chunk: every read ahead of the first MFMA
@@ -346,7 +351,7 @@ __device__ __forceinline__ void conv_mfma(int in_off, int out_off, const float* 
                 if (16 * (nt0 + nt) + jl < HW) {
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
-                        float* o = lds_f32 + out_off + (((mt0 + m) * 4 + r) * HW + 16 * (nt0 + nt) + jl) * 4 + kq;
+                        float* o = lds_f32 + out_off + (((mt0 + m) * 4 + r) * HWp + 16 * (nt0 + nt) + jl) * 4 + kq;
                         *o = accumulate ? (*o + acc[m][nt][r]) : acc[m][nt][r];
                     }
                 }
@@ -356,23 +361,20 @@ __device__ __forceinline__ void conv_mfma(int in_off, int out_off, const float* 
 
 template <int MT>
 __device__ __forceinline__ void conv_mfma_nt(int in_off, int out_off, const float* __restrict__ Wt, int Cin, int Cout, int taps,
-                                             int nb_off, int zero_off, int HW, bool accumulate) {
+                                             int nb_off, int NP, int HW, bool accumulate) {
     const int ntl = (HW + 15) >> 4;
     const int ngr = (Cout >> 4) / MT;
     int nsplit = (NW + ngr - 1) / ngr;            // enough work items for every wave
     nsplit = nsplit < 1 ? 1 : (nsplit > ntl ? ntl : nsplit);
     switch ((ntl + nsplit - 1) / nsplit) {
-        case 1: conv_mfma<MT, 1>(in_off, out_off, Wt, Cin, Cout, taps, nb_off, zero_off, HW, accumulate, nsplit); break;
-        case 2: conv_mfma<MT, 2>(in_off, out_off, Wt, Cin, Cout, taps, nb_off, zero_off, HW, accumulate, nsplit); break;
-        case 3: conv_mfma<MT, 3>(in_off, out_off, Wt, Cin, Cout, taps, nb_off, zero_off, HW, accumulate, nsplit); break;
-        case 4: conv_mfma<MT, 4>(in_off, out_off, Wt, Cin, Cout, taps, nb_off, zero_off, HW, accumulate, nsplit); break;
-        case 5: conv_mfma<MT, 5>(in_off, out_off, Wt, Cin, Cout, taps, nb_off, zero_off, HW, accumulate, nsplit); break;
-        default: conv_mfma<MT, 6>(in_off, out_off, Wt, Cin, Cout, taps, nb_off, zero_off, HW, accumulate, nsplit); break;
+        case 1: conv_mfma<MT, 1>(in_off, out_off, Wt, Cin, Cout, taps, nb_off, NP, HW, accumulate, nsplit); break;
+        case 2: conv_mfma<MT, 2>(in_off, out_off, Wt, Cin, Cout, taps, nb_off, NP, HW, accumulate, nsplit); break;
+        case 3: conv_mfma<MT, 3>(in_off, out_off, Wt, Cin, Cout, taps, nb_off, NP, HW, accumulate, nsplit); break;
+        case 4: conv_mfma<MT, 4>(in_off, out_off, Wt, Cin, Cout, taps, nb_off, NP, HW, accumulate, nsplit); break;
+        case 5: conv_mfma<MT, 5>(in_off, out_off, Wt, Cin, Cout, taps, nb_off, NP, HW, accumulate, nsplit); break;
+        default: conv_mfma<MT, 6>(in_off, out_off, Wt, Cin, Cout, taps, nb_off, NP, HW, accumulate, nsplit); break;
     }
 }
-
-// offset (floats from the neighbour table) of the 16 zero bytes behind it
-__device__ __forceinline__ int zero_floats(int HW) { return ((9 * HW + 1) / 2 + 3) & ~3; }
 
 // The convs of a Q16 network (net.h) whose output channels fill whole 16-row tiles go to the matrix cores; the rest (the
 // head convs with 1 and 2 output channels, toy networks) stay on the vector ALU.
@@ -381,11 +383,11 @@ __device__ __forceinline__ void conv_lds(const float* in, float* out, const floa
     if (fp32_conv_on_mfma(q16, Cout)) {
         const int io = (int)(in - lds_f32), oo = (int)(out - lds_f32);
         const int no = (int)(reinterpret_cast<const float*>(nb) - lds_f32);
-        const int zo = no + zero_floats(HW);   // k_net_fp32 clears them
-        if ((Cout & 31) == 0 && Cout >= 128) conv_mfma_nt<2>(io, oo, Wt, Cin, Cout, taps, no, zo, HW, accumulate);
-        else conv_mfma_nt<1>(io, oo, Wt, Cin, Cout, taps, no, zo, HW, accumulate);
+        const int NP = ((HW + 15) >> 4) << 4;
+        if ((Cout & 31) == 0 && Cout >= 128) conv_mfma_nt<2>(io, oo, Wt, Cin, Cout, taps, no, NP, HW, accumulate);
+        else conv_mfma_nt<1>(io, oo, Wt, Cin, Cout, taps, no, NP, HW, accumulate);
     } else {
-        conv_valu(in, out, Wt, Cin, CoutPad, Cout, taps, nb, HW, accumulate, q16);
+        conv_valu(in, out, Wt, Cin, CoutPad, Cout, taps, nb, HW, accumulate);
     }
 }
 
@@ -433,7 +435,7 @@ __device__ __forceinline__ void broadcast_mfma(int in_off, int out_off, const fl
             const int p = 4 * ks + kq;
             const bool pok = p < HW;
             const int pc = pok ? p : HW - 1;
-            float bvl = lds_f32[in_off + (q16 ? fp32_q16_index(ch, pc, HW) : ch * HW + pc)];
+            float bvl = lds_f32[in_off + (q16 ? fp32_q16_index(ch, pc, HW + 1) : ch * HW + pc)];
             float av[NTQ];
 #pragma unroll
             for (int mt = 0; mt < NTQ; mt++) {
@@ -450,7 +452,7 @@ __device__ __forceinline__ void broadcast_mfma(int in_off, int out_off, const fl
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int q = 16 * mt + 4 * kq + r;
-                if (q < HW) lds_f32[out_off + (q16 ? fp32_q16_index(ch, q, HW) : ch * HW + q)] = acc[mt][r] + b[q];
+                if (q < HW) lds_f32[out_off + (q16 ? fp32_q16_index(ch, q, HW + 1) : ch * HW + q)] = acc[mt][r] + b[q];
             }
     }
     __syncthreads();
@@ -492,26 +494,39 @@ __global__ __launch_bounds__(NT) void k_net_fp32(NetDims d, const NetProgramF32*
     const int c_pad = prog->c_pad, cb_pad = prog->cb_pad;
     const bool q16 = fp32_q16(C, Cb, HW);   // activations, hidden-state slots and gamma / beta in Q16 order (net.h)
 
-    for (int i = tid; i < 9 * HW; i += NT) {
-        const int t = i / HW, p = i - t * HW;
+    // Q16 images: planes of HWp = HW + 1 cells, the last one the zero cell (conv_mfma); the neighbour table [tap][NP] names it
+    // for off-board taps and for the columns that pad the last tile.  Otherwise [tap][HW] with -1 for off-board (conv_valu).
+    const int HWp = q16 ? HW + 1 : HW;
+    const int NP = q16 ? ((HW + 15) >> 4) << 4 : HW;
+    for (int i = tid; i < 9 * NP; i += NT) {
+        const int t = i / NP, p = i - t * NP;
         const int y = p / d.Wd + t / 3 - 1, x = p % d.Wd + t % 3 - 1;
-        nb[i] = (y >= 0 && y < d.H && x >= 0 && x < d.Wd) ? (short)(y * d.Wd + x) : (short)-1;
+        const bool on = p < HW && y >= 0 && y < d.H && x >= 0 && x < d.Wd;
+        nb[i] = on ? (short)(y * d.Wd + x) : (short)(q16 ? HW : -1);
     }
-    if (tid < 4) reinterpret_cast<float*>(nb)[zero_floats(HW) + tid] = 0.f;   // what off-board taps of the MFMA convs read
+    unsigned padmask = 0;   // ln_relu: which of this thread's float4 items are zero cells (item j = float4 tid + j NT of a buffer)
+    if (q16) {
+        for (int j = 0; j < 3072 / NT; j++) padmask |= ((tid + j * NT) % HWp == HW ? 1u : 0u) << j;
+        const int planes = (buf_floats >> 2) / HWp;   // the zero cells of X, T1, T2: nothing below writes anything but 0 there
+        for (int i = tid; i < 3 * planes; i += NT) {
+            const int bf = i / planes, pl = i - bf * planes;
+            reinterpret_cast<float4*>(smem + bf * buf_floats)[pl * HWp + HW] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
     const TowerOff& tw = INITIAL ? prog->rep : prog->dyn;
-    // element j of a Q16 image -> its channel and cell
+    // element j of a Q16 image in LDS (planes of HWp cells) -> its channel and cell (cell HW = the zero cell)
     auto unq16 = [&](int j, int& c, int& p) {
-        const int G = j / (16 * HW), r = j - G * 16 * HW, c4 = r / (4 * HW), r2 = r - c4 * 4 * HW;
+        const int G = j / (16 * HWp), r = j - G * 16 * HWp, c4 = r / (4 * HWp), r2 = r - c4 * 4 * HWp;
         p = r2 >> 2;
         c = 16 * G + 4 * (r2 & 3) + c4;
     };
     if (INITIAL) {
         const float* src = io.obs + (long long)g * d.O * HW;
         if (q16) {   // the observation planes, zero-filled to whole groups of 16 channels
-            for (int j = tid; j < ((d.O + 15) & ~15) * HW; j += NT) {
+            for (int j = tid; j < ((d.O + 15) & ~15) * HWp; j += NT) {
                 int c, p;
                 unq16(j, c, p);
-                T1[j] = c < d.O ? src[c * HW + p] : 0.f;
+                T1[j] = (c < d.O && p < HW) ? src[c * HW + p] : 0.f;
             }
         } else {
             for (int i = tid; i < d.O * HW; i += NT) T1[i] = src[i];
@@ -530,8 +545,8 @@ __global__ __launch_bounds__(NT) void k_net_fp32(NetDims d, const NetProgramF32*
                 }
 #pragma unroll
                 for (int j = 0; j < 6; j++) {
-                    const int i = i0 + tid + j * NT;
-                    if (i < n4) reinterpret_cast<float4*>(T1)[i] = v[j];
+                    const int i = i0 + tid + j * NT;   // slot order: planes of HW cells; LDS: planes of HWp
+                    if (i < n4) reinterpret_cast<float4*>(T1)[q16 ? i + i / HW : i] = v[j];
                 }
             }
         } else {
@@ -539,10 +554,10 @@ __global__ __launch_bounds__(NT) void k_net_fp32(NetDims d, const NetProgramF32*
         }
         const int cell = io.action_cells[io.action[g]];
         if (q16) {   // ConcatInputsBlock: the action planes are channels C .. C + a - 1 of group C / 16
-            for (int j = tid; j < ((d.a + 15) & ~15) * HW; j += NT) {
+            for (int j = tid; j < ((d.a + 15) & ~15) * HWp; j += NT) {
                 int c, p;
                 unq16(j, c, p);
-                T1[C * HW + j] = (c < d.a && c * HW + p == cell) ? 1.f : 0.f;
+                T1[C * HWp + j] = (c < d.a && p < HW && c * HW + p == cell) ? 1.f : 0.f;
             }
         } else {
             for (int i = tid; i < d.a * HW; i += NT) T1[C * HW + i] = (i == cell) ? 1.f : 0.f;  // ConcatInputsBlock
@@ -592,11 +607,11 @@ __global__ __launch_bounds__(NT) void k_net_fp32(NetDims d, const NetProgramF32*
                 cv_w = j == 0 ? b.c1 : b.c2;
                 cv_acc = j == 2;
             }
-            if (btype >= 0) TL(ln_relu(smem + ln_in, smem + ln_out, ln_c * HW, wb + ln_g, wb + ln_b, red);)
+            if (btype >= 0) TL(ln_relu(smem + ln_in, smem + ln_out, ln_c * HWp, wb + ln_g, wb + ln_b, red, ln_c * HW, q16 ? HWp : 0, padmask);)
             if (btype == 1 && j == 1) TB(broadcast_any(T2, T1, wb + b.bw, wb + b.bb, C, HW, q16);)
             if (do_conv) TC(conv_lds(smem + cv_in, smem + cv_out, wb + cv_w, cv_cin, cv_pad, cv_cout, cv_taps, nb, HW, cv_acc, q16);)
             if (btype < 0 && !INITIAL) {  // StartResidualBlock: conv3x3(cat[s, a]) + s
-                for (int i = tid; i < C * HW; i += NT) X[i] += T1[i];
+                for (int i = tid; i < C * HWp; i += NT) X[i] += T1[i];
                 __syncthreads();
             }
         }
@@ -607,18 +622,38 @@ __global__ __launch_bounds__(NT) void k_net_fp32(NetDims d, const NetProgramF32*
 #endif
     {
         float mn = INFINITY, mx = -INFINITY;
-        for (int i = tid; i < C * HW; i += NT) {
-            mn = fminf(mn, X[i]);
-            mx = fmaxf(mx, X[i]);
-        }
-        mn = block_min(mn, red);
-        mx = block_max(mx, red);
-        const float dd = fmaxf(mx - mn, 1e-5f);
         float* dst = io.pool + (long long)io.dst_slot[g] * C * HW;
-        for (int i = tid; i < C * HW; i += NT) {
-            const float y = (X[i] - mn) / dd;
-            X[i] = y;
-            dst[i] = y;
+        if (q16) {   // float4 i of the state in slot order (planes of HW cells) = float4 i + i / HW of X (planes of HWp)
+            const int n4 = (C * HW) >> 2;
+            const float4* X4 = reinterpret_cast<const float4*>(X);
+            for (int i = tid; i < n4; i += NT) {
+                const float4 x = X4[i + i / HW];
+                mn = fminf(mn, fminf(fminf(x.x, x.y), fminf(x.z, x.w)));
+                mx = fmaxf(mx, fmaxf(fmaxf(x.x, x.y), fmaxf(x.z, x.w)));
+            }
+            mn = block_min(mn, red);
+            mx = block_max(mx, red);
+            const float dd = fmaxf(mx - mn, 1e-5f);
+            for (int i = tid; i < n4; i += NT) {
+                const int k = i + i / HW;
+                const float4 x = X4[k];
+                const float4 y = make_float4((x.x - mn) / dd, (x.y - mn) / dd, (x.z - mn) / dd, (x.w - mn) / dd);
+                reinterpret_cast<float4*>(X)[k] = y;
+                reinterpret_cast<float4*>(dst)[i] = y;
+            }
+        } else {
+            for (int i = tid; i < C * HW; i += NT) {
+                mn = fminf(mn, X[i]);
+                mx = fmaxf(mx, X[i]);
+            }
+            mn = block_min(mn, red);
+            mx = block_max(mx, red);
+            const float dd = fmaxf(mx - mn, 1e-5f);
+            for (int i = tid; i < C * HW; i += NT) {
+                const float y = (X[i] - mn) / dd;
+                X[i] = y;
+                dst[i] = y;
+            }
         }
         __syncthreads();
     }
@@ -639,7 +674,7 @@ __global__ __launch_bounds__(NT) void k_net_fp32(NetDims d, const NetProgramF32*
             const int part = it / HW, p = it - part * HW;
             float a0 = 0.f, a1 = 0.f, a2 = 0.f;
             for (int c = part; c < C; c += np) {
-                const float x = X[q16 ? fp32_q16_index(c, p, HW) : c * HW + p];
+                const float x = X[q16 ? fp32_q16_index(c, p, HWp) : c * HW + p];
                 const float4 wp = *reinterpret_cast<const float4*>(wb + h.pconv + (long long)c * 4);
                 const float wv = wb[h.vconv + (long long)c * 4];
                 a0 = fmaf(x, wp.x, a0);
@@ -728,7 +763,7 @@ size_t fp32_buf_floats(const NetDims& d) {
     int extra = d.a > d.O ? d.a : d.O;
     size_t n = (size_t)(d.C + extra) * d.HW;
     if (fp32_q16(d.C, d.Cb, d.HW)) {   // conv0's input image in whole groups of 16 channels
-        const size_t rec = (size_t)(d.C + ((d.a + 15) & ~15)) * d.HW, ini = (size_t)((d.O + 15) & ~15) * d.HW;
+        const size_t rec = (size_t)(d.C + ((d.a + 15) & ~15)) * (d.HW + 1), ini = (size_t)((d.O + 15) & ~15) * (d.HW + 1);   // + zero cells
         n = rec > ini ? rec : ini;
     }
     const size_t a4 = ((size_t)d.A + 3) & ~(size_t)3;
@@ -738,7 +773,7 @@ size_t fp32_buf_floats(const NetDims& d) {
 }
 
 size_t fp32_lds_bytes(const NetDims& d) {
-    return (3 * fp32_buf_floats(d) + 8) * sizeof(float) + (size_t)9 * d.HW * sizeof(short) + 48;   // + the 16 zero bytes
+    return (3 * fp32_buf_floats(d) + 8) * sizeof(float) + (size_t)9 * (((d.HW + 15) >> 4) << 4) * sizeof(short) + 16;   // + the neighbour table
 }
 
 namespace {

@@ -42,7 +42,10 @@ __global__ __launch_bounds__(512) void k(const float* __restrict__ W, float* out
                 if (g == 3)
                     for (int nt = 0; nt < 3; nt++) base[nt] = basen[nt], gstr[nt] = gstrn[nt];
             }
-            if (MODE & 1) {
+            if (MODE & 64) {
+#pragma unroll
+                for (int nt = 0; nt < 3; nt++) bv[nt] = *(const f32x4*)((const char*)lds + (__umul24(g, 64 * 81) + base[nt]));
+            } else if (MODE & 1) {
                 const int G = (g + 1) & 3;
 #pragma unroll
                 for (int nt = 0; nt < 3; nt++) bn[nt] = *(const f32x4*)((const char*)lds + (__umul24(G, (MODE & 8) ? gstr[nt] : 64 * 81) + base[nt]));
@@ -56,11 +59,11 @@ __global__ __launch_bounds__(512) void k(const float* __restrict__ W, float* out
             for (int s = 0; s < 4; s++)
 #pragma unroll
                 for (int nt = 0; nt < 3; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g][s], bv[nt][s], acc[nt], 0, 0, 0);
-            if (MODE & 1) {
+            if ((MODE & 65) == 1) {
 #pragma unroll
                 for (int nt = 0; nt < 3; nt++) bv[nt] = bn[nt];
             }
-            if ((MODE & 24) == 8) __builtin_amdgcn_sched_barrier(0);
+            if ((MODE & 56) == 8) __builtin_amdgcn_sched_barrier(0);   // bit 5: no fence at all
             if (MODE & 16) {   // pin: an MFMA, then a slice of the other work, 12 times
 #pragma unroll
                 for (int i = 0; i < 12; i++) {
@@ -132,6 +135,8 @@ int main() {
         run<7, 2>(th, W, out, cyc, 64);
         run<15>(th, W, out, cyc, 1152);
         run<31>(th, W, out, cyc, 1152);
+        run<47>(th, W, out, cyc, 1152);
+        run<71>(th, W, out, cyc, 1152);
         run<2>(th, W, out, cyc, 1152);
     }
     return 0;
