@@ -24,9 +24,8 @@ namespace {
 #if defined(MZ_X_NT)   // experiment: waves per workgroup
 constexpr int NT = MZ_X_NT;
 #else
-constexpr int NT = 512;
+constexpr int NT = 512;   // 8 waves, two per SIMD: the partner wave covers LDS / L2 latency of the MFMA convs
 #endif
-//   // 8 waves, two per SIMD: the partner wave covers LDS / L2 latency of the MFMA convs
 constexpr int NW = NT / 64;
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
@@ -81,8 +80,11 @@ __device__ __forceinline__ float block_min(float v, float* red) {
 // a Q16 image (net.h) whose planes carry a zero cell behind the board (cell hwp - 1 of every hwp): those cells hold 0 and
 // have gamma = beta = 0, so they add nothing to the sum and come out as 0, but they are not samples: `count` = the real
 // element count, and the centred squares skip them (padmask: bit j = this thread's j-th float4 of the fast path is one).
+// presum != nullptr: the conv that wrote `in` left the NW per-wave sums of what it stored there (conv_mfma), published by
+// its closing barrier: the mean comes from those and the first block reduction (two barriers) is not run.
 __device__ __forceinline__ void ln_relu(const float* in, float* out, int n, const float* __restrict__ gamma,
-                        const float* __restrict__ beta, float* red, int count = 0, int hwp = 0, unsigned padmask = 0) {
+                        const float* __restrict__ beta, float* red, int count = 0, int hwp = 0, unsigned padmask = 0,
+                        const float* presum = nullptr) {
     if (count == 0) count = n;
     // Fast path (every tower LayerNorm: n = channels * HW with channels % 4 == 0, at most LNI float4 items per thread): the
     // thread's items are read once and stay in registers through both statistics passes and the normalisation, and its
@@ -103,15 +105,28 @@ __device__ __forceinline__ void ln_relu(const float* in, float* out, int n, cons
         for (int j = 0; j < LNI; j++) {
             const int i = threadIdx.x + j * NT;
             const int ic = i < n4 ? i : 0;
+#if defined(MZ_X_NOGB)   // experiment: no gamma / beta traffic
+            g[j] = (f32x4v){1.f, 1.f, 1.f, 1.f};
+            bb[j] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+#else
             g[j] = g4[ic];
             bb[j] = b4[ic];
+#endif
             v[j] = in4[ic];
         }
-        float s = 0.f;
+        float mean;
+        if (presum) {
+            float t = 0.f;
 #pragma unroll
-        for (int j = 0; j < LNI; j++)
-            if (threadIdx.x + j * NT < n4) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
-        const float mean = block_sum(s, red) / (float)count;
+            for (int w = 0; w < NW; w++) t += presum[w];
+            mean = t / (float)count;
+        } else {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < LNI; j++)
+                if (threadIdx.x + j * NT < n4) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+            mean = block_sum(s, red) / (float)count;
+        }
         float q = 0.f;
 #pragma unroll
         for (int j = 0; j < LNI; j++)
@@ -228,7 +243,7 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
 // branches and not EXEC masks.
 template <int MT, int NTW>
 __device__ __forceinline__ void conv_mfma(int in_off, int out_off, const float* __restrict__ Wt, int Cin, int Cout, int taps,
-                                          int nb_off, int NP, int HW, bool accumulate, int nsplit) {
+                                          int nb_off, int NP, int HW, bool accumulate, int nsplit, int csum_off) {
     constexpr int CH = 16 / MT;                 // k-steps per chunk: 16 A registers in use, 16 in flight
     constexpr int NG = CH / 4;                  // groups of 16 input channels per chunk
     in_off = uni(in_off), out_off = uni(out_off), Cin = uni(Cin), Cout = uni(Cout), taps = uni(taps), nb_off = uni(nb_off);
@@ -246,6 +261,7 @@ __device__ __forceinline__ void conv_mfma(int in_off, int out_off, const float* 
     const int KS = ((Cin + 15) >> 4) << 2;      // k-steps per tap: whole groups
     const int nc16 = (Cin + 63) >> 6;           // 4 KiB weight units per (tap, row tile): api.cpp:pack_conv
     const int ngroups = nmt / MT;
+    float wsum = 0.f;   // sum of everything this wave stores: the next LayerNorm's mean (ln_relu presum)
     for (int it = wave; it < ngroups * nsplit; it += NW) {
         const int mt0 = (it % ngroups) * MT, nt0 = (it / ngroups) * NTW;
         f32x4v acc[MT][NTW];
@@ -352,40 +368,45 @@ __device__ __forceinline__ void conv_mfma(int in_off, int out_off, const float* 
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
                         float* o = lds_f32 + out_off + (((mt0 + m) * 4 + r) * HWp + 16 * (nt0 + nt) + jl) * 4 + kq;
-                        *o = accumulate ? (*o + acc[m][nt][r]) : acc[m][nt][r];
+                        const float val = accumulate ? (*o + acc[m][nt][r]) : acc[m][nt][r];
+                        *o = val;
+                        wsum += val;
                     }
                 }
     }
+    wsum = wave_sum_f(wsum);
+    if (lane == 0) lds_f32[csum_off + wave] = wsum;
     __syncthreads();
 }
 
 template <int MT>
 __device__ __forceinline__ void conv_mfma_nt(int in_off, int out_off, const float* __restrict__ Wt, int Cin, int Cout, int taps,
-                                             int nb_off, int NP, int HW, bool accumulate) {
+                                             int nb_off, int NP, int HW, bool accumulate, int csum_off) {
     const int ntl = (HW + 15) >> 4;
     const int ngr = (Cout >> 4) / MT;
     int nsplit = (NW + ngr - 1) / ngr;            // enough work items for every wave
     nsplit = nsplit < 1 ? 1 : (nsplit > ntl ? ntl : nsplit);
     switch ((ntl + nsplit - 1) / nsplit) {
-        case 1: conv_mfma<MT, 1>(in_off, out_off, Wt, Cin, Cout, taps, nb_off, NP, HW, accumulate, nsplit); break;
-        case 2: conv_mfma<MT, 2>(in_off, out_off, Wt, Cin, Cout, taps, nb_off, NP, HW, accumulate, nsplit); break;
-        case 3: conv_mfma<MT, 3>(in_off, out_off, Wt, Cin, Cout, taps, nb_off, NP, HW, accumulate, nsplit); break;
-        case 4: conv_mfma<MT, 4>(in_off, out_off, Wt, Cin, Cout, taps, nb_off, NP, HW, accumulate, nsplit); break;
-        case 5: conv_mfma<MT, 5>(in_off, out_off, Wt, Cin, Cout, taps, nb_off, NP, HW, accumulate, nsplit); break;
-        default: conv_mfma<MT, 6>(in_off, out_off, Wt, Cin, Cout, taps, nb_off, NP, HW, accumulate, nsplit); break;
+        case 1: conv_mfma<MT, 1>(in_off, out_off, Wt, Cin, Cout, taps, nb_off, NP, HW, accumulate, nsplit, csum_off); break;
+        case 2: conv_mfma<MT, 2>(in_off, out_off, Wt, Cin, Cout, taps, nb_off, NP, HW, accumulate, nsplit, csum_off); break;
+        case 3: conv_mfma<MT, 3>(in_off, out_off, Wt, Cin, Cout, taps, nb_off, NP, HW, accumulate, nsplit, csum_off); break;
+        case 4: conv_mfma<MT, 4>(in_off, out_off, Wt, Cin, Cout, taps, nb_off, NP, HW, accumulate, nsplit, csum_off); break;
+        case 5: conv_mfma<MT, 5>(in_off, out_off, Wt, Cin, Cout, taps, nb_off, NP, HW, accumulate, nsplit, csum_off); break;
+        default: conv_mfma<MT, 6>(in_off, out_off, Wt, Cin, Cout, taps, nb_off, NP, HW, accumulate, nsplit, csum_off); break;
     }
 }
 
 // The convs of a Q16 network (net.h) whose output channels fill whole 16-row tiles go to the matrix cores; the rest (the
 // head convs with 1 and 2 output channels, toy networks) stay on the vector ALU.
 __device__ __forceinline__ void conv_lds(const float* in, float* out, const float* __restrict__ Wt, int Cin, int CoutPad, int Cout, int taps,
-                         const short* nb, int HW, bool accumulate, bool q16) {
+                         const short* nb, int HW, bool accumulate, bool q16, const float* csum) {
     if (fp32_conv_on_mfma(q16, Cout)) {
+        const int co = (int)(csum - lds_f32);
         const int io = (int)(in - lds_f32), oo = (int)(out - lds_f32);
         const int no = (int)(reinterpret_cast<const float*>(nb) - lds_f32);
         const int NP = ((HW + 15) >> 4) << 4;
-        if ((Cout & 31) == 0 && Cout >= 128) conv_mfma_nt<2>(io, oo, Wt, Cin, Cout, taps, no, NP, HW, accumulate);
-        else conv_mfma_nt<1>(io, oo, Wt, Cin, Cout, taps, no, NP, HW, accumulate);
+        if ((Cout & 31) == 0 && Cout >= 128) conv_mfma_nt<2>(io, oo, Wt, Cin, Cout, taps, no, NP, HW, accumulate, co);
+        else conv_mfma_nt<1>(io, oo, Wt, Cin, Cout, taps, no, NP, HW, accumulate, co);
     } else {
         conv_valu(in, out, Wt, Cin, CoutPad, Cout, taps, nb, HW, accumulate);
     }
@@ -489,7 +510,8 @@ __global__ __launch_bounds__(NT) void k_net_fp32(NetDims d, const NetProgramF32*
     float* T1 = X + buf_floats;
     float* T2 = T1 + buf_floats;
     float* red = T2 + buf_floats;
-    short* nb = reinterpret_cast<short*>(red + 8);
+    float* csum = red + 8;   // per-wave sums of the last MFMA conv's output (conv_mfma -> ln_relu)
+    short* nb = reinterpret_cast<short*>(red + 16);
     const int tid = threadIdx.x;
     const int c_pad = prog->c_pad, cb_pad = prog->cb_pad;
     const bool q16 = fp32_q16(C, Cb, HW);   // activations, hidden-state slots and gamma / beta in Q16 order (net.h)
@@ -572,6 +594,7 @@ __global__ __launch_bounds__(NT) void k_net_fp32(NetDims d, const NetProgramF32*
     // they saved: every call spilled and refilled ~100 callee-saved VGPRs per lane through scratch memory.)
     // step (-1, 0) = the input conv; a bottleneck block = 4 steps, a broadcast block = 3.
     const int oX = 0, oT1 = buf_floats, oT2 = 2 * buf_floats;
+    bool sum_ready = false;   // csum holds the sums of the buffer the next LayerNorm reads
     for (int r = -1; r < d.R; r++) {
         const BlockOff& b = tw.blocks[r < 0 ? 0 : r];
         const int btype = r < 0 ? -1 : b.type;
@@ -607,9 +630,14 @@ __global__ __launch_bounds__(NT) void k_net_fp32(NetDims d, const NetProgramF32*
                 cv_w = j == 0 ? b.c1 : b.c2;
                 cv_acc = j == 2;
             }
-            if (btype >= 0) TL(ln_relu(smem + ln_in, smem + ln_out, ln_c * HWp, wb + ln_g, wb + ln_b, red, ln_c * HW, q16 ? HWp : 0, padmask);)
+            if (btype >= 0) TL(ln_relu(smem + ln_in, smem + ln_out, ln_c * HWp, wb + ln_g, wb + ln_b, red, ln_c * HW, q16 ? HWp : 0, padmask,
+                                       sum_ready ? csum : nullptr);)
+            sum_ready = false;
             if (btype == 1 && j == 1) TB(broadcast_any(T2, T1, wb + b.bw, wb + b.bb, C, HW, q16);)
-            if (do_conv) TC(conv_lds(smem + cv_in, smem + cv_out, wb + cv_w, cv_cin, cv_pad, cv_cout, cv_taps, nb, HW, cv_acc, q16);)
+            if (do_conv) {
+                TC(conv_lds(smem + cv_in, smem + cv_out, wb + cv_w, cv_cin, cv_pad, cv_cout, cv_taps, nb, HW, cv_acc, q16, csum);)
+                sum_ready = fp32_conv_on_mfma(q16, cv_cout) && !(btype < 0 && !INITIAL);   // (the StartResidual add changes X)
+            }
             if (btype < 0 && !INITIAL) {  // StartResidualBlock: conv3x3(cat[s, a]) + s
                 for (int i = tid; i < C * HWp; i += NT) X[i] += T1[i];
                 __syncthreads();
@@ -773,7 +801,7 @@ size_t fp32_buf_floats(const NetDims& d) {
 }
 
 size_t fp32_lds_bytes(const NetDims& d) {
-    return (3 * fp32_buf_floats(d) + 8) * sizeof(float) + (size_t)9 * (((d.HW + 15) >> 4) << 4) * sizeof(short) + 16;   // + the neighbour table
+    return (3 * fp32_buf_floats(d) + 16) * sizeof(float) + (size_t)9 * (((d.HW + 15) >> 4) << 4) * sizeof(short) + 16;   // + the neighbour table
 }
 
 namespace {
