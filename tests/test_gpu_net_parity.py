@@ -48,12 +48,16 @@ def _specs():
         "tiny_bcast": netspec.spec_tiny(),                                    # 12 channels, broadcast block at idx 1
         "tiny_single": netspec.spec_tiny(two_players=False, action_space=20, hw=(4, 5), obs=2, act=3,
                                          residuals=3, broadcast_every_n=0, channels=8, bottleneck=4),
-        # shapes only the fp32 path takes: its MFMA convs with one and two row tiles, a ragged input-channel count, two column
-        # tiles; and a net whose bottleneck convs stay on the vector ALU while the C-wide ones go to the matrix cores
+        # shapes only the fp32 path takes: channel counts in multiples of 16 = its Q16 order and MFMA convs (net.h) with one and
+        # two row tiles, a ragged input-channel count, two column tiles, a broadcast block; a net whose bottleneck is not a
+        # multiple of 16 (everything on the vector ALU in [channel][cell] order); and a Q16 net whose C-wide LayerNorms
+        # (176 x 70 / 4 = 3080 float4 items) are beyond the register path of ln_relu while its bottleneck ones are inside it
         "tiny_fp32_mfma": netspec.spec_tiny(action_space=21, hw=(4, 5), obs=5, act=2, residuals=3, broadcast_every_n=2,
                                             channels=32, bottleneck=16),
         "tiny_fp32_mixed": netspec.spec_tiny(two_players=False, action_space=10, hw=(3, 3), obs=3, act=1, residuals=2,
                                              broadcast_every_n=0, channels=16, bottleneck=8),
+        "fp32_q16_wide": netspec.spec_tiny(action_space=70, hw=(3, 23), obs=3, act=1, residuals=2, broadcast_every_n=2,
+                                           channels=176, bottleneck=64),
         "tictactoe": netspec.spec_tictactoe(),
         "go5": netspec.spec_go5(),
         "go9": netspec.spec_go9(),
@@ -101,8 +105,8 @@ def _check(spec, precision, B, seed, ln_jitter=0.1, weights=None):
     ctx.close()
 
 
-@pytest.mark.parametrize("name", ["tiny_bcast", "tiny_single", "tiny_fp32_mfma", "tiny_fp32_mixed", "tictactoe", "go5", "go9",
-                                  "pegsolitair"])
+@pytest.mark.parametrize("name", ["tiny_bcast", "tiny_single", "tiny_fp32_mfma", "tiny_fp32_mixed", "fp32_q16_wide", "tictactoe",
+                                  "go5", "go9", "pegsolitair"])
 def test_fp32_forward_matches_oracle(name):
     _check(_specs()[name], capi.PRECISION_FP32, B=6, seed=3)
 
