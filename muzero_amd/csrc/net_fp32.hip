@@ -1,8 +1,10 @@
-// fp32 forward of initialInference (f o h) and recurrentInference (f o g): one 256-thread workgroup
+// fp32 forward of initialInference (f o h) and recurrentInference (f o g): one 512-thread workgroup
 // per board, the whole board's activations resident in LDS from the first conv to the heads, so the
 // only HBM traffic per sample is the parent hidden state in, the child hidden state out and the
-// (L2-resident) weights.  This is the exact-precision path (MZ_PRECISION_FP32); the bf16 MFMA path
-// in net_mfma.hip is checked against it and against the CPU oracle.
+// (mostly L2-resident) weights.  This is the exact-precision path (MZ_PRECISION_FP32: fp32 operands,
+// v_mfma_f32_16x16x4_f32 convs); the 16-bit MFMA paths in net_mfma.hip are checked against it and
+// against the CPU oracle.  DESIGN.md §5 describes the layout (Q16 order with a zero cell per plane)
+// and what was measured.
 //
 // Reference math (platform/.../agent/d_model/djl/blocks/): RepresentationBlock.java:38-40,
 // DynamicsBlock.java:40-42, StartResidualBlock.java:53-62, ResidualTower.java:30-40,
