@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Error statistics of a 16-bit network path against oracle/net.py over random weights, LayerNorm jitter and batches:
+"""Error statistics of a network path (16-bit, or the exact fp32 one) against oracle/net.py over random weights, LayerNorm jitter and batches:
 max over cases of |got - ref| / (1 + |ref|) (the quantity an rtol = atol bar bounds) per game and output, for the initial and
-the recurrent step.  python3 tools/fuzz_net_stats.py [cases] [seed0] [f16|bf16]"""
+the recurrent step.  python3 tools/fuzz_net_stats.py [cases] [seed0] [f16|bf16|fp32]"""
 import os
 import sys
 
@@ -26,7 +26,7 @@ def sq(a, r):   # (sum of squares, count) of the same quantity: for the rms the 
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 9000
-    prec = {"f16": capi.PRECISION_F16, "bf16": capi.PRECISION_BF16}[sys.argv[3] if len(sys.argv) > 3 else "f16"]
+    prec = {"f16": capi.PRECISION_F16, "bf16": capi.PRECISION_BF16, "fp32": capi.PRECISION_FP32}[sys.argv[3] if len(sys.argv) > 3 else "f16"]
     specs = T._specs()
     names = ["tictactoe", "go5", "go9", "pegsolitair"]
     worst = {n: dict(h=0.0, l=0.0, p=0.0, v=0.0) for n in names}
