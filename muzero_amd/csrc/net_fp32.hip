@@ -407,7 +407,19 @@ __device__ __forceinline__ void conv_lds(const float* in, float* out, const floa
         const int io = (int)(in - lds_f32), oo = (int)(out - lds_f32);
         const int no = (int)(reinterpret_cast<const float*>(nb) - lds_f32);
         const int NP = ((HW + 15) >> 4) << 4;
-        if ((Cout & 31) == 0 && Cout >= 128) conv_mfma_nt<2>(io, oo, Wt, Cin, Cout, taps, no, NP, HW, accumulate, co);
+        // Two row tiles per wave halve the B reads per MFMA, more column tiles per wave the (dearer) A loads: two row tiles
+        // only where that still leaves a wave three column tiles, or as many as one row tile would (Go 5x5, 256 channels on
+        // 2 column tiles: 15.5 -> 13.6 ms per 4096 boards with one row tile x 2 column tiles instead of 2 x 1).
+        const int ntl = NP >> 4, nmt = Cout >> 4;
+        auto ntw_of = [&](int mt) {
+            const int ngr = nmt / mt;
+            int ns = (NW + ngr - 1) / ngr;
+            ns = ns < 1 ? 1 : (ns > ntl ? ntl : ns);
+            return (ntl + ns - 1) / ns;
+        };
+        const int n1 = ntw_of(1);
+        const bool two = (Cout & 31) == 0 && Cout >= 128 && ntw_of(2) >= (n1 < 3 ? n1 : 3);
+        if (two) conv_mfma_nt<2>(io, oo, Wt, Cin, Cout, taps, no, NP, HW, accumulate, co);
         else conv_mfma_nt<1>(io, oo, Wt, Cin, Cout, taps, no, NP, HW, accumulate, co);
     } else {
         conv_valu(in, out, Wt, Cin, CoutPad, Cout, taps, nb, HW, accumulate);
